@@ -1,0 +1,13 @@
+"""fabstir-vectordb_amd — MI355X-native engine for fabstir-vectordb's hybrid HNSW/IVF
+distance-computation hot path.
+
+Layout: csrc/ (HIP kernels + the C ABI of include/fvdb.h), lib/ (built libfvdb_hip.so),
+engine.py (ctypes view of the C ABI), host/ (C++ mirror of the reference's IVFIndex /
+HNSWIndex / HybridIndex for this path) and index.py (its Python surface).
+
+The directory name carries a hyphen, so import it through `fvdb_import.py` at the repo root
+(`import fvdb_import; pkg = fvdb_import.load()`), which registers it as `fabstir_vectordb_amd`.
+"""
+from . import _capi  # noqa: F401
+from .engine import *  # noqa: F401,F403
+from .engine import Context, DeviceIVF, RowStore  # noqa: F401

@@ -1,0 +1,1252 @@
+// fvdb_hip.cpp — C ABI (include/fvdb.h) over the HIP kernels.  gfx950 only; compiled with
+//   hipcc -x hip -O3 -ffp-contract=off --offload-arch=gfx950
+// Host side here is plumbing: memory, launch order, list bookkeeping.  All arithmetic on
+// vectors happens in the kernels; there is no CPU fallback anywhere in this library.
+#include "../../include/fvdb.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels_misc.h"
+#include "kernels_scan.h"
+
+using namespace fvdb;
+
+namespace {
+
+struct DBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = std::max<size_t>(bytes + bytes / 4, 256);
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const { return (T*)p; }
+};
+
+struct HBuf {  // pinned host staging
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct fvdb_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int num_cus = 256;
+  std::string err;
+  HBuf h_stage;     // host->device staging for host-pointer entry points
+  bool profiling = false;
+};
+
+#define HIPCHK(ctx, call)                                                                     \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+      return e_ == hipErrorOutOfMemory ? FVDB_E_OOM : FVDB_E_HIP;                             \
+    }                                                                                         \
+  } while (0)
+
+#define FAIL(ctx, code, msg) \
+  do {                       \
+    (ctx)->err = (msg);      \
+    return (code);           \
+  } while (0)
+
+static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// A pool of 64-row blocks in HBM (layout: common.h PoolView).
+struct Pool {
+  uint32_t d4 = 0;
+  uint32_t cap_blocks = 0, used_blocks = 0;
+  float4* data = nullptr;
+  uint64_t* ids = nullptr;
+  uint64_t* valid = nullptr;
+  size_t block_f4() const { return (size_t)d4 * 64; }
+  PoolView view() const { return PoolView{data, ids, valid, d4}; }
+  void release() {
+    if (data) (void)hipFree(data);
+    if (ids) (void)hipFree(ids);
+    if (valid) (void)hipFree(valid);
+    data = nullptr;
+    ids = nullptr;
+    valid = nullptr;
+    cap_blocks = used_blocks = 0;
+  }
+  // grow to at least `blocks` capacity, preserving contents (stream-ordered copies)
+  int reserve(fvdb_ctx* ctx, uint32_t blocks) {
+    if (blocks <= cap_blocks) return FVDB_OK;
+    uint32_t ncap = std::max<uint32_t>(blocks, cap_blocks + cap_blocks / 2 + 16);
+    float4* nd = nullptr;
+    uint64_t* ni = nullptr;
+    uint64_t* nv = nullptr;
+    HIPCHK(ctx, hipMalloc(&nd, (size_t)ncap * block_f4() * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&ni, (size_t)ncap * 64 * sizeof(uint64_t)));
+    HIPCHK(ctx, hipMalloc(&nv, (size_t)ncap * sizeof(uint64_t)));
+    HIPCHK(ctx, hipMemsetAsync(nv, 0, (size_t)ncap * sizeof(uint64_t), ctx->stream));
+    if (used_blocks) {
+      HIPCHK(ctx, hipMemcpyAsync(nd, data, (size_t)used_blocks * block_f4() * sizeof(float4),
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(ni, ids, (size_t)used_blocks * 64 * sizeof(uint64_t), hipMemcpyDeviceToDevice,
+                                 ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(nv, valid, (size_t)used_blocks * sizeof(uint64_t), hipMemcpyDeviceToDevice,
+                                 ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (data) (void)hipFree(data);
+    if (ids) (void)hipFree(ids);
+    if (valid) (void)hipFree(valid);
+    data = nd;
+    ids = ni;
+    valid = nv;
+    cap_blocks = ncap;
+    return FVDB_OK;
+  }
+};
+
+struct fvdb_ivf {
+  fvdb_ctx* ctx = nullptr;
+  uint32_t d = 0, dpad = 0, d4 = 0, nlist = 0;
+  bool trained = false;
+
+  // centroid table: row-major copy (host + device) and a blocked pool scanned as "list 0"
+  std::vector<float> h_centroids;
+  DBuf d_centroids_rm;   // [nlist][d]
+  Pool cpool;
+  DBuf c_off, c_blocks, c_glob;  // single-list table for the centroid pool
+
+  // inverted lists: paged blocks
+  Pool pool;
+  std::vector<std::vector<uint32_t>> list_blocks;  // per list: pool block indices
+  std::vector<uint32_t> list_len;                  // rows per list (including soft-deleted)
+  uint64_t total_rows = 0;
+  uint32_t max_list_blocks = 0;
+  bool table_dirty = true;
+  DBuf t_off, t_blocks, t_glob;  // device list table + logical (global) block counts
+  std::vector<uint32_t> glob_blocks_host;  // empty => local sizes
+  bool glob_set = false;
+
+  // per-search scratch
+  DBuf s_q, s_cpart, s_probes, s_cnt, s_fill, s_eoff, s_ioff, s_entries, s_part, s_scalars, s_ceoff, s_cioff;
+  DBuf s_in, s_slots, s_ids, s_clusters, s_out_ids, s_out_dist, s_out_cnt, s_cdist;
+  fvdb_search_stats last_stats{};
+  float stage_ms[5] = {0, 0, 0, 0, 0};  // coarse scan, coarse merge, plan, fine scan, fine merge
+  uint64_t stage_calls = 0;
+  hipEvent_t sev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+struct fvdb_store {
+  fvdb_ctx* ctx = nullptr;
+  uint32_t d = 0, dpad = 0;
+  uint64_t rows = 0, cap = 0;
+  float* data = nullptr;  // [cap][dpad]
+  DBuf s_q, s_cand, s_out, s_in;
+};
+
+struct fvdb_scorer {
+  fvdb_store* store = nullptr;
+  uint32_t max_B = 0, max_C = 0;
+  float* d_q = nullptr;        // [max_B][dpad]
+  uint32_t* h_cand = nullptr;  // pinned, mapped
+  float* h_dist = nullptr;     // pinned, mapped
+  uint32_t* d_cand = nullptr;  // device aliases of the mapped buffers
+  float* d_dist = nullptr;
+  DBuf s_rows;
+};
+
+// ---------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct ScanLaunch {
+  PoolView pool;
+  const uint32_t* list_off;
+  const uint32_t* list_blocks;
+  uint32_t nlist;
+  const uint32_t* entry_off;
+  const uint32_t* item_off;
+  const uint2* entries;
+  const uint32_t* n_items;
+  uint32_t* head;
+  const float* queries;
+  uint32_t dpad, segb, k, nprobe, maxsegs;
+  uint2* part;
+};
+
+inline int kr_for(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : 4); }
+inline uint32_t q_for(uint32_t k) { return k <= 64 ? 16u : (k <= 128 ? 8u : 4u); }
+
+template <int Q, int KR>
+void launch_scan_t(fvdb_ctx* ctx, const ScanLaunch& s) {
+  const uint32_t grid = (uint32_t)ctx->num_cus * 8u;
+  hipLaunchKernelGGL((scan_topk_kernel<Q, KR>), dim3(grid), dim3(256), 0, ctx->stream, s.pool.data, s.pool.valid,
+                     s.pool.d4, s.list_off, s.list_blocks, s.nlist, s.entry_off, s.item_off, (const u32x2*)s.entries,
+                     s.n_items, s.head, s.queries, s.dpad, s.segb, s.k, s.nprobe, s.maxsegs, (u32x2*)s.part);
+}
+
+void launch_scan(fvdb_ctx* ctx, const ScanLaunch& s) {
+  switch (kr_for(s.k)) {
+    case 1: launch_scan_t<16, 1>(ctx, s); break;
+    case 2: launch_scan_t<8, 2>(ctx, s); break;
+    default: launch_scan_t<4, 4>(ctx, s); break;
+  }
+}
+
+void launch_merge(fvdb_ctx* ctx, const MergeArgs& m) {
+  const uint32_t grid = cdiv(m.B, 4);
+  switch (kr_for(m.k)) {
+    case 1: hipLaunchKernelGGL((merge_topk_kernel<1>), dim3(grid), dim3(256), 0, ctx->stream, m); break;
+    case 2: hipLaunchKernelGGL((merge_topk_kernel<2>), dim3(grid), dim3(256), 0, ctx->stream, m); break;
+    default: hipLaunchKernelGGL((merge_topk_kernel<4>), dim3(grid), dim3(256), 0, ctx->stream, m); break;
+  }
+}
+
+// scalars block layout (uint32): [0]=coarse n_items [1]=coarse head [2]=fine n_items [3]=fine head
+//                                 [4..9] = stats (3 x u64)
+constexpr size_t kScalarsBytes = 64;
+
+int upload_table(fvdb_ivf* ivf) {
+  fvdb_ctx* ctx = ivf->ctx;
+  if (!ivf->table_dirty) return FVDB_OK;
+  std::vector<uint32_t> off(ivf->nlist + 1, 0), blocks;
+  std::vector<uint32_t> glob(ivf->nlist, 0);
+  uint32_t mx = 0;
+  for (uint32_t L = 0; L < ivf->nlist; ++L) {
+    off[L] = (uint32_t)blocks.size();
+    blocks.insert(blocks.end(), ivf->list_blocks[L].begin(), ivf->list_blocks[L].end());
+    mx = std::max<uint32_t>(mx, (uint32_t)ivf->list_blocks[L].size());
+    glob[L] = ivf->glob_set ? ivf->glob_blocks_host[L] : (uint32_t)ivf->list_blocks[L].size();
+  }
+  off[ivf->nlist] = (uint32_t)blocks.size();
+  ivf->max_list_blocks = mx;
+  HIPCHK(ctx, ivf->t_off.ensure(off.size() * 4));
+  HIPCHK(ctx, ivf->t_blocks.ensure(std::max<size_t>(blocks.size(), 1) * 4));
+  HIPCHK(ctx, ivf->t_glob.ensure(glob.size() * 4));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->t_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (!blocks.empty())
+    HIPCHK(ctx, hipMemcpyAsync(ivf->t_blocks.p, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->t_glob.p, glob.data(), glob.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+  ivf->table_dirty = false;
+  return FVDB_OK;
+}
+
+// queries as [B][dpad] in HBM: q_dev itself when d is a multiple of 4, else a padded copy
+int padded_queries(fvdb_ivf* ivf, const float* q_dev, uint32_t B, const float** out) {
+  fvdb_ctx* ctx = ivf->ctx;
+  if (ivf->d == ivf->dpad) {
+    *out = q_dev;
+    return FVDB_OK;
+  }
+  HIPCHK(ctx, ivf->s_q.ensure((size_t)B * ivf->dpad * 4));
+  const uint64_t tot = (uint64_t)B * ivf->dpad;
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, ctx->stream, q_dev, ivf->d, ivf->dpad,
+                     (uint64_t)B, ivf->s_q.as<float>());
+  *out = ivf->s_q.as<float>();
+  return FVDB_OK;
+}
+
+// Coarse stage: rank the centroid table for B queries, keep kc nearest per query.
+// Writes u32 cluster ids to out_probes[B][kc] (probe order) and, optionally, their distances.
+int run_coarse(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t kc, uint32_t* out_probes, float* out_dist) {
+  fvdb_ctx* ctx = ivf->ctx;
+  const uint32_t cblocks = ivf->cpool.used_blocks;
+  const uint32_t segb = 1, Q = q_for(kc);
+  const uint32_t maxsegs = cblocks;
+  HIPCHK(ctx, ivf->s_cpart.ensure((size_t)B * maxsegs * kc * 8));
+  HIPCHK(ctx, ivf->s_entries.ensure((size_t)B * std::max<uint32_t>(kc, 1) * 8));
+  HIPCHK(ctx, ivf->s_ceoff.ensure(16));
+  HIPCHK(ctx, ivf->s_cioff.ensure(16));
+  HIPCHK(ctx, ivf->s_scalars.ensure(kScalarsBytes));
+  uint32_t* scal = ivf->s_scalars.as<uint32_t>();
+  hipLaunchKernelGGL(plan_all_kernel, dim3(cdiv(std::max<uint32_t>(B, 1), 256)), dim3(256), 0, ctx->stream, B, cblocks,
+                     segb, Q, ivf->s_ceoff.as<uint32_t>(), ivf->s_cioff.as<uint32_t>(), ivf->s_entries.as<uint2>(),
+                     scal + 0, scal + 1);
+  ScanLaunch s{ivf->cpool.view(), ivf->c_off.as<uint32_t>(), ivf->c_blocks.as<uint32_t>(), 1,
+               ivf->s_ceoff.as<uint32_t>(), ivf->s_cioff.as<uint32_t>(), ivf->s_entries.as<uint2>(), scal + 0,
+               scal + 1, qpad, ivf->dpad, segb, kc, 1, maxsegs, ivf->s_cpart.as<uint2>()};
+  if (ctx->profiling) (void)hipEventRecord(ivf->sev[0], ctx->stream);
+  launch_scan(ctx, s);
+  if (ctx->profiling) (void)hipEventRecord(ivf->sev[1], ctx->stream);
+  MergeArgs m{};
+  m.pool = ivf->cpool.view();
+  m.lists = ListTable{ivf->c_off.as<uint32_t>(), ivf->c_blocks.as<uint32_t>(), 1};
+  m.probes = nullptr;
+  m.glob_blocks = ivf->c_glob.as<uint32_t>();
+  m.part = ivf->s_cpart.as<uint2>();
+  m.B = B;
+  m.k = kc;
+  m.nprobe = 1;
+  m.maxsegs = maxsegs;
+  m.segb = segb;
+  m.out_probes = out_probes;
+  m.out_dist = out_dist;
+  launch_merge(ctx, m);
+  if (ctx->profiling) (void)hipEventRecord(ivf->sev[2], ctx->stream);
+  HIPCHK(ctx, hipGetLastError());
+  return FVDB_OK;
+}
+
+uint32_t pick_segb(fvdb_ivf* ivf, uint32_t B, uint32_t nprobe) {
+  // enough (segment, group) items to fill 256 CUs x 32 waves, without shredding long lists
+  const uint64_t pairs = (uint64_t)B * nprobe;
+  if (ivf->max_list_blocks >= 4096) return 16;
+  if (pairs >= 4096) return 4;
+  if (pairs >= 512) return 2;
+  return 1;
+}
+
+// Fine stage for B queries whose probes[B][np] are already in HBM.
+int run_fine(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t np, const uint32_t* probes,
+             uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys) {
+  fvdb_ctx* ctx = ivf->ctx;
+  const uint32_t nlist = ivf->nlist;
+  const uint32_t segb = pick_segb(ivf, B, np), Q = q_for(k);
+  const uint32_t maxsegs = std::max<uint32_t>(1, cdiv(ivf->max_list_blocks, segb));
+  const uint64_t part_elems = (uint64_t)B * np * maxsegs * k;
+  if (part_elems >= (1ull << 32)) FAIL(ctx, FVDB_E_UNSUPPORTED, "batch too large for one launch (sub-batch it)");
+  HIPCHK(ctx, ivf->s_cnt.ensure((size_t)nlist * 4));
+  HIPCHK(ctx, ivf->s_fill.ensure((size_t)nlist * 4));
+  HIPCHK(ctx, ivf->s_eoff.ensure((size_t)(nlist + 1) * 4));
+  HIPCHK(ctx, ivf->s_ioff.ensure((size_t)(nlist + 1) * 4));
+  HIPCHK(ctx, ivf->s_entries.ensure((size_t)B * np * 8));
+  HIPCHK(ctx, ivf->s_part.ensure((size_t)part_elems * 8));
+  HIPCHK(ctx, ivf->s_scalars.ensure(kScalarsBytes));
+  uint32_t* scal = ivf->s_scalars.as<uint32_t>();
+  const uint32_t n = B * np;
+  HIPCHK(ctx, hipMemsetAsync(ivf->s_cnt.p, 0, (size_t)nlist * 4, ctx->stream));
+  hipLaunchKernelGGL(plan_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, probes, n,
+                     ivf->s_cnt.as<uint32_t>());
+  hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ivf->s_cnt.as<uint32_t>(),
+                     ivf->t_off.as<uint32_t>(), nlist, segb, Q, ivf->s_eoff.as<uint32_t>(),
+                     ivf->s_ioff.as<uint32_t>(), ivf->s_fill.as<uint32_t>(), scal + 2, scal + 3,
+                     (unsigned long long*)(scal + 4));
+  hipLaunchKernelGGL(plan_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, probes, n, np,
+                     ivf->s_eoff.as<uint32_t>(), ivf->s_fill.as<uint32_t>(), ivf->s_entries.as<uint2>());
+  if (ctx->profiling) (void)hipEventRecord(ivf->sev[3], ctx->stream);
+  ScanLaunch s{ivf->pool.view(), ivf->t_off.as<uint32_t>(), ivf->t_blocks.as<uint32_t>(), nlist,
+               ivf->s_eoff.as<uint32_t>(), ivf->s_ioff.as<uint32_t>(), ivf->s_entries.as<uint2>(), scal + 2,
+               scal + 3, qpad, ivf->dpad, segb, k, np, maxsegs, ivf->s_part.as<uint2>()};
+  launch_scan(ctx, s);
+  if (ctx->profiling) (void)hipEventRecord(ivf->sev[4], ctx->stream);
+  MergeArgs m{};
+  m.pool = ivf->pool.view();
+  m.lists = ListTable{ivf->t_off.as<uint32_t>(), ivf->t_blocks.as<uint32_t>(), nlist};
+  m.probes = probes;
+  m.glob_blocks = ivf->t_glob.as<uint32_t>();
+  m.part = ivf->s_part.as<uint2>();
+  m.B = B;
+  m.k = k;
+  m.nprobe = np;
+  m.maxsegs = maxsegs;
+  m.segb = segb;
+  m.out_ids = out_ids;
+  m.out_dist = out_dist;
+  m.out_counts = out_counts;
+  m.out_keys = out_keys;
+  launch_merge(ctx, m);
+  if (ctx->profiling) (void)hipEventRecord(ivf->sev[5], ctx->stream);
+  HIPCHK(ctx, hipGetLastError());
+  return FVDB_OK;
+}
+
+int finish_profile(fvdb_ivf* ivf, bool coarse, bool fine) {
+  fvdb_ctx* ctx = ivf->ctx;
+  if (!ctx->profiling) return FVDB_OK;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  if (coarse) {
+    (void)hipEventElapsedTime(&ms, ivf->sev[0], ivf->sev[1]);
+    ivf->stage_ms[0] += ms;
+    (void)hipEventElapsedTime(&ms, ivf->sev[1], ivf->sev[2]);
+    ivf->stage_ms[1] += ms;
+  }
+  if (fine) {
+    if (coarse) {
+      (void)hipEventElapsedTime(&ms, ivf->sev[2], ivf->sev[3]);
+      ivf->stage_ms[2] += ms;
+    }
+    (void)hipEventElapsedTime(&ms, ivf->sev[3], ivf->sev[4]);
+    ivf->stage_ms[3] += ms;
+    (void)hipEventElapsedTime(&ms, ivf->sev[4], ivf->sev[5]);
+    ivf->stage_ms[4] += ms;
+  }
+  ivf->stage_calls += 1;
+  return FVDB_OK;
+}
+
+// largest sub-batch whose fine-stage partial buffer stays under ~1 GiB
+uint32_t sub_batch(fvdb_ivf* ivf, uint32_t B, uint32_t k, uint32_t np) {
+  const uint32_t segb = pick_segb(ivf, B, np);
+  const uint64_t per_q = (uint64_t)np * std::max<uint32_t>(1, cdiv(ivf->max_list_blocks, segb)) * k * 8;
+  uint64_t fit = (1ull << 30) / std::max<uint64_t>(per_q, 1);
+  fit = std::max<uint64_t>(fit, 1);
+  fit = std::min<uint64_t>(fit, 65536);
+  return (uint32_t)std::min<uint64_t>(fit, B);
+}
+
+int check_finite(fvdb_ctx* ctx, const float* x, uint64_t n) {
+  for (uint64_t i = 0; i < n; ++i)
+    if (!std::isfinite(x[i])) FAIL(ctx, FVDB_E_NONFINITE, "non-finite input value");
+  return FVDB_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// context
+// =============================================================================================
+extern "C" {
+
+const char* fvdb_version(void) { return "fvdb-hip 0.1 (gfx950)"; }
+
+int fvdb_ctx_create(int device, fvdb_ctx** out) {
+  if (!out) return FVDB_E_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return FVDB_E_HIP;
+  fvdb_ctx* ctx = new (std::nothrow) fvdb_ctx();
+  if (!ctx) return FVDB_E_OOM;
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return FVDB_E_HIP;
+  }
+  (void)hipEventCreate(&ctx->ev0);
+  (void)hipEventCreate(&ctx->ev1);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+  *out = ctx;
+  return FVDB_OK;
+}
+
+void fvdb_ctx_destroy(fvdb_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->h_stage.release();
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int fvdb_ctx_synchronize(fvdb_ctx* ctx) {
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+void* fvdb_ctx_stream(fvdb_ctx* ctx) { return (void*)ctx->stream; }
+const char* fvdb_last_error(fvdb_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int fvdb_ctx_set_profiling(fvdb_ctx* ctx, int on) {
+  ctx->profiling = on != 0;
+  return FVDB_OK;
+}
+
+int fvdb_dev_alloc(fvdb_ctx* ctx, size_t bytes, void** out) {
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMalloc(out, std::max<size_t>(bytes, 16)));
+  return FVDB_OK;
+}
+int fvdb_dev_free(fvdb_ctx* ctx, void* p) {
+  HIPCHK(ctx, hipFree(p));
+  return FVDB_OK;
+}
+int fvdb_dev_upload(fvdb_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+int fvdb_dev_download(fvdb_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+int fvdb_timer_start(fvdb_ctx* ctx) {
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return FVDB_OK;
+}
+int fvdb_timer_stop_ms(fvdb_ctx* ctx, float* out_ms) {
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+  HIPCHK(ctx, hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
+  return FVDB_OK;
+}
+
+// =============================================================================================
+// IVF
+// =============================================================================================
+int fvdb_ivf_create(fvdb_ctx* ctx, uint32_t d, uint32_t nlist, fvdb_ivf** out) {
+  if (!ctx || !out) return FVDB_E_INVALID;
+  *out = nullptr;
+  if (d == 0 || nlist == 0) FAIL(ctx, FVDB_E_INVALID, "d and nlist must be > 0");
+  if (d > 2048 * 4) FAIL(ctx, FVDB_E_INVALID, "d too large");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  fvdb_ivf* ivf = new (std::nothrow) fvdb_ivf();
+  if (!ivf) return FVDB_E_OOM;
+  ivf->ctx = ctx;
+  ivf->d = d;
+  ivf->d4 = (d + 3) / 4;
+  ivf->dpad = ivf->d4 * 4;
+  ivf->nlist = nlist;
+  ivf->list_blocks.assign(nlist, {});
+  ivf->list_len.assign(nlist, 0);
+  ivf->pool.d4 = ivf->d4;
+  ivf->cpool.d4 = ivf->d4;
+  for (auto& e : ivf->sev) (void)hipEventCreate(&e);
+  *out = ivf;
+  return FVDB_OK;
+}
+
+void fvdb_ivf_destroy(fvdb_ivf* ivf) {
+  if (!ivf) return;
+  (void)hipSetDevice(ivf->ctx->device);
+  (void)hipStreamSynchronize(ivf->ctx->stream);
+  ivf->pool.release();
+  ivf->cpool.release();
+  DBuf* bufs[] = {&ivf->d_centroids_rm, &ivf->c_off, &ivf->c_blocks, &ivf->c_glob, &ivf->t_off, &ivf->t_blocks,
+                  &ivf->t_glob, &ivf->s_q, &ivf->s_cpart, &ivf->s_probes, &ivf->s_cnt, &ivf->s_fill, &ivf->s_eoff,
+                  &ivf->s_ioff, &ivf->s_entries, &ivf->s_part, &ivf->s_scalars, &ivf->s_ceoff, &ivf->s_cioff,
+                  &ivf->s_in, &ivf->s_slots, &ivf->s_ids, &ivf->s_clusters, &ivf->s_out_ids, &ivf->s_out_dist,
+                  &ivf->s_out_cnt, &ivf->s_cdist};
+  for (DBuf* b : bufs) b->release();
+  for (auto& e : ivf->sev)
+    if (e) (void)hipEventDestroy(e);
+  delete ivf;
+}
+
+static int install_centroids(fvdb_ivf* ivf, const float* d_rowmajor /* device [nlist][d] */) {
+  fvdb_ctx* ctx = ivf->ctx;
+  const uint32_t nlist = ivf->nlist, cblocks = cdiv(nlist, 64);
+  int rc = ivf->cpool.reserve(ctx, cblocks);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemsetAsync(ivf->cpool.valid, 0, (size_t)ivf->cpool.cap_blocks * 8, ctx->stream));
+  ivf->cpool.used_blocks = cblocks;
+  std::vector<uint32_t> slots(nlist), off{0, cblocks}, blocks(cblocks), glob{cblocks};
+  for (uint32_t i = 0; i < nlist; ++i) slots[i] = i;
+  for (uint32_t i = 0; i < cblocks; ++i) blocks[i] = i;
+  HIPCHK(ctx, ivf->s_slots.ensure((size_t)nlist * 4));
+  HIPCHK(ctx, ivf->c_off.ensure(8));
+  HIPCHK(ctx, ivf->c_blocks.ensure((size_t)cblocks * 4));
+  HIPCHK(ctx, ivf->c_glob.ensure(4));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->s_slots.p, slots.data(), (size_t)nlist * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->c_off.p, off.data(), 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->c_blocks.p, blocks.data(), (size_t)cblocks * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->c_glob.p, glob.data(), 4, hipMemcpyHostToDevice, ctx->stream));
+  const uint64_t threads = (uint64_t)nlist * ivf->d4;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, ctx->stream, d_rowmajor, ivf->d,
+                     ivf->d4, (uint64_t)nlist, ivf->s_slots.as<uint32_t>(), (const uint64_t*)nullptr,
+                     ivf->cpool.data, ivf->cpool.ids, (unsigned long long*)ivf->cpool.valid);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ivf->trained = true;
+  return FVDB_OK;
+}
+
+static void reset_lists(fvdb_ivf* ivf) {
+  ivf->list_blocks.assign(ivf->nlist, {});
+  ivf->list_len.assign(ivf->nlist, 0);
+  ivf->total_rows = 0;
+  ivf->pool.used_blocks = 0;
+  ivf->max_list_blocks = 0;
+  ivf->table_dirty = true;
+}
+
+int fvdb_ivf_set_centroids(fvdb_ivf* ivf, const float* centroids) {
+  fvdb_ctx* ctx = ivf->ctx;
+  if (!centroids) FAIL(ctx, FVDB_E_INVALID, "null centroids");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)ivf->nlist * ivf->d;
+  int rc = check_finite(ctx, centroids, n);
+  if (rc) return rc;
+  ivf->h_centroids.assign(centroids, centroids + n);
+  HIPCHK(ctx, ivf->d_centroids_rm.ensure(n * 4));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->d_centroids_rm.p, centroids, n * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = install_centroids(ivf, ivf->d_centroids_rm.as<float>());
+  if (rc) return rc;
+  reset_lists(ivf);
+  if (ivf->pool.valid && ivf->pool.cap_blocks)
+    HIPCHK(ctx, hipMemsetAsync(ivf->pool.valid, 0, (size_t)ivf->pool.cap_blocks * 8, ctx->stream));
+  return FVDB_OK;
+}
+
+int fvdb_ivf_get_centroids(fvdb_ivf* ivf, float* out) {
+  if (!ivf->trained) FAIL(ivf->ctx, FVDB_E_NOT_TRAINED, "index not trained");
+  std::memcpy(out, ivf->h_centroids.data(), ivf->h_centroids.size() * 4);
+  return FVDB_OK;
+}
+
+int fvdb_ivf_clear(fvdb_ivf* ivf) {
+  fvdb_ctx* ctx = ivf->ctx;
+  reset_lists(ivf);
+  if (ivf->pool.valid && ivf->pool.cap_blocks)
+    HIPCHK(ctx, hipMemsetAsync(ivf->pool.valid, 0, (size_t)ivf->pool.cap_blocks * 8, ctx->stream));
+  return FVDB_OK;
+}
+
+int fvdb_ivf_reserve(fvdb_ivf* ivf, uint64_t n_rows) {
+  HIPCHK(ivf->ctx, hipSetDevice(ivf->ctx->device));
+  // every list may end in a partly filled block
+  return ivf->pool.reserve(ivf->ctx, cdiv(n_rows, 64) + ivf->nlist);
+}
+
+int fvdb_ivf_list_sizes(fvdb_ivf* ivf, uint64_t* out) {
+  for (uint32_t L = 0; L < ivf->nlist; ++L) out[L] = ivf->list_len[L];
+  return FVDB_OK;
+}
+uint64_t fvdb_ivf_total_rows(fvdb_ivf* ivf) { return ivf->total_rows; }
+
+int fvdb_ivf_set_global_list_sizes(fvdb_ivf* ivf, const uint64_t* sizes) {
+  ivf->glob_blocks_host.resize(ivf->nlist);
+  for (uint32_t L = 0; L < ivf->nlist; ++L) ivf->glob_blocks_host[L] = cdiv(sizes[L], 64);
+  ivf->glob_set = true;
+  ivf->table_dirty = true;
+  return FVDB_OK;
+}
+
+// device-side assign: clusters for n rows already in HBM (row-major [n][d])
+static int assign_dev(fvdb_ivf* ivf, const float* x_dev, uint64_t n, uint32_t* out_dev) {
+  fvdb_ctx* ctx = ivf->ctx;
+  const uint32_t step = 65536;
+  for (uint64_t o = 0; o < n; o += step) {
+    const uint32_t B = (uint32_t)std::min<uint64_t>(step, n - o);
+    const float* qpad = nullptr;
+    int rc = padded_queries(ivf, x_dev + o * ivf->d, B, &qpad);
+    if (rc) return rc;
+    rc = run_coarse(ivf, qpad, B, 1, out_dev + o, nullptr);
+    if (rc) return rc;
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return FVDB_OK;
+}
+
+int fvdb_ivf_assign(fvdb_ivf* ivf, const float* x, uint64_t n, uint32_t* out_cluster) {
+  fvdb_ctx* ctx = ivf->ctx;
+  if (!ivf->trained) FAIL(ctx, FVDB_E_NOT_TRAINED, "index not trained");
+  if (n == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = check_finite(ctx, x, n * ivf->d);
+  if (rc) return rc;
+  HIPCHK(ctx, ivf->s_in.ensure(n * ivf->d * 4));
+  HIPCHK(ctx, ivf->s_clusters.ensure(n * 4));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->s_in.p, x, n * ivf->d * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = assign_dev(ivf, ivf->s_in.as<float>(), n, ivf->s_clusters.as<uint32_t>());
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(out_cluster, ivf->s_clusters.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+
+// rows already staged in s_in (device, row-major); clusters on host
+static int append_staged(fvdb_ivf* ivf, const uint64_t* ids, uint64_t n, const uint32_t* cluster, uint32_t* out_pos) {
+  fvdb_ctx* ctx = ivf->ctx;
+  // count new blocks first so the pool grows once
+  std::vector<uint32_t> add_len(ivf->nlist, 0);
+  for (uint64_t i = 0; i < n; ++i) {
+    if (cluster[i] >= ivf->nlist) FAIL(ctx, FVDB_E_INVALID, "cluster id out of range");
+    add_len[cluster[i]]++;
+  }
+  uint64_t new_blocks = 0;
+  for (uint32_t L = 0; L < ivf->nlist; ++L)
+    new_blocks += cdiv((uint64_t)ivf->list_len[L] + add_len[L], 64) - ivf->list_blocks[L].size();
+  if ((uint64_t)ivf->pool.used_blocks + new_blocks >= (1ull << 26)) FAIL(ctx, FVDB_E_UNSUPPORTED, "pool too large");
+  int rc = ivf->pool.reserve(ctx, ivf->pool.used_blocks + (uint32_t)new_blocks);
+  if (rc) return rc;
+  std::vector<uint32_t> slots(n);
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint32_t L = cluster[i];
+    const uint32_t pos = ivf->list_len[L]++;
+    if ((pos & 63) == 0) ivf->list_blocks[L].push_back(ivf->pool.used_blocks++);
+    slots[i] = ivf->list_blocks[L][pos >> 6] * 64 + (pos & 63);
+    if (out_pos) out_pos[i] = pos;
+  }
+  ivf->total_rows += n;
+  ivf->table_dirty = true;
+  HIPCHK(ctx, ivf->s_slots.ensure(n * 4));
+  HIPCHK(ctx, ivf->s_ids.ensure(n * 8));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->s_slots.p, slots.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (ids) HIPCHK(ctx, hipMemcpyAsync(ivf->s_ids.p, ids, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  const uint64_t threads = n * ivf->d4;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, ctx->stream, ivf->s_in.as<float>(),
+                     ivf->d, ivf->d4, n, ivf->s_slots.as<uint32_t>(), ids ? ivf->s_ids.as<uint64_t>() : nullptr,
+                     ivf->pool.data, ivf->pool.ids, (unsigned long long*)ivf->pool.valid);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+
+int fvdb_ivf_add_assigned(fvdb_ivf* ivf, const float* x, const uint64_t* ids, uint64_t n, const uint32_t* cluster,
+                          uint32_t* out_pos) {
+  fvdb_ctx* ctx = ivf->ctx;
+  if (!ivf->trained) FAIL(ctx, FVDB_E_NOT_TRAINED, "index not trained");
+  if (n == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = check_finite(ctx, x, n * ivf->d);
+  if (rc) return rc;
+  HIPCHK(ctx, ivf->s_in.ensure(n * ivf->d * 4));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->s_in.p, x, n * ivf->d * 4, hipMemcpyHostToDevice, ctx->stream));
+  return append_staged(ivf, ids, n, cluster, out_pos);
+}
+
+int fvdb_ivf_add(fvdb_ivf* ivf, const float* x, const uint64_t* ids, uint64_t n, uint32_t* out_cluster,
+                 uint32_t* out_pos) {
+  fvdb_ctx* ctx = ivf->ctx;
+  if (!ivf->trained) FAIL(ctx, FVDB_E_NOT_TRAINED, "index not trained");
+  if (n == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = check_finite(ctx, x, n * ivf->d);
+  if (rc) return rc;
+  HIPCHK(ctx, ivf->s_in.ensure(n * ivf->d * 4));
+  HIPCHK(ctx, ivf->s_clusters.ensure(n * 4));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->s_in.p, x, n * ivf->d * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = assign_dev(ivf, ivf->s_in.as<float>(), n, ivf->s_clusters.as<uint32_t>());
+  if (rc) return rc;
+  std::vector<uint32_t> cl(n);
+  HIPCHK(ctx, hipMemcpyAsync(cl.data(), ivf->s_clusters.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (out_cluster) std::memcpy(out_cluster, cl.data(), n * 4);
+  return append_staged(ivf, ids, n, cl.data(), out_pos);
+}
+
+int fvdb_ivf_set_deleted(fvdb_ivf* ivf, const uint32_t* cluster, const uint32_t* pos, uint64_t n, int deleted) {
+  fvdb_ctx* ctx = ivf->ctx;
+  if (n == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<uint32_t> slots(n);
+  for (uint64_t i = 0; i < n; ++i) {
+    if (cluster[i] >= ivf->nlist || pos[i] >= ivf->list_len[cluster[i]]) FAIL(ctx, FVDB_E_NOT_FOUND, "no such row");
+    slots[i] = ivf->list_blocks[cluster[i]][pos[i] >> 6] * 64 + (pos[i] & 63);
+  }
+  HIPCHK(ctx, ivf->s_slots.ensure(n * 4));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->s_slots.p, slots.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(set_valid_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, ivf->s_slots.as<uint32_t>(), n,
+                     deleted, (unsigned long long*)ivf->pool.valid);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+
+static int search_common(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t k, uint32_t nprobe, bool all,
+                         uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys) {
+  fvdb_ctx* ctx = ivf->ctx;
+  if (!ivf->trained) FAIL(ctx, FVDB_E_NOT_TRAINED, "index not trained");
+  if (k == 0 || k > FVDB_MAX_K) FAIL(ctx, FVDB_E_UNSUPPORTED, "k must be in 1..FVDB_MAX_K");
+  if (B == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const uint32_t np = all ? ivf->nlist : std::min(nprobe, ivf->nlist);
+  if (np == 0) FAIL(ctx, FVDB_E_INVALID, "nprobe must be > 0");
+  if (!all && np > FVDB_MAX_K) FAIL(ctx, FVDB_E_UNSUPPORTED, "nprobe above FVDB_MAX_K");
+  int rc = upload_table(ivf);
+  if (rc) return rc;
+  const uint32_t step = sub_batch(ivf, B, k, np);
+  for (uint32_t o = 0; o < B; o += step) {
+    const uint32_t b = std::min(step, B - o);
+    const float* qpad = nullptr;
+    rc = padded_queries(ivf, q_dev + (size_t)o * ivf->d, b, &qpad);
+    if (rc) return rc;
+    HIPCHK(ctx, ivf->s_probes.ensure((size_t)b * np * 4));
+    if (all) {
+      hipLaunchKernelGGL(probes_all_kernel, dim3(cdiv((uint64_t)b * np, 256)), dim3(256), 0, ctx->stream, b, np,
+                         ivf->s_probes.as<uint32_t>());
+      if (ctx->profiling) (void)hipEventRecord(ivf->sev[2], ctx->stream);
+    } else {
+      rc = run_coarse(ivf, qpad, b, np, ivf->s_probes.as<uint32_t>(), nullptr);
+      if (rc) return rc;
+    }
+    rc = run_fine(ivf, qpad, b, k, np, ivf->s_probes.as<uint32_t>(), out_ids ? out_ids + (size_t)o * k : nullptr,
+                  out_dist ? out_dist + (size_t)o * k : nullptr, out_counts ? out_counts + o : nullptr,
+                  out_keys ? out_keys + (size_t)o * k : nullptr);
+    if (rc) return rc;
+    rc = finish_profile(ivf, !all, true);
+    if (rc) return rc;
+  }
+  return FVDB_OK;
+}
+
+int fvdb_ivf_search_dev(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t k, uint32_t nprobe,
+                        uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev, uint64_t* out_keys_dev) {
+  return search_common(ivf, q_dev, B, k, nprobe, false, out_ids_dev, out_dist_dev, out_counts_dev, out_keys_dev);
+}
+
+int fvdb_ivf_search_all_dev(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t k, uint64_t* out_ids_dev,
+                            float* out_dist_dev, uint32_t* out_counts_dev) {
+  return search_common(ivf, q_dev, B, k, 0, true, out_ids_dev, out_dist_dev, out_counts_dev, nullptr);
+}
+
+static int search_host(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t k, uint32_t nprobe, bool all,
+                       uint64_t* out_ids, float* out_dist, uint32_t* out_counts) {
+  fvdb_ctx* ctx = ivf->ctx;
+  if (!ivf->trained) FAIL(ctx, FVDB_E_NOT_TRAINED, "index not trained");
+  if (B == 0) return FVDB_OK;
+  if (k == 0 || k > FVDB_MAX_K) FAIL(ctx, FVDB_E_UNSUPPORTED, "k must be in 1..FVDB_MAX_K");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = check_finite(ctx, q, (uint64_t)B * ivf->d);
+  if (rc) return rc;
+  HIPCHK(ctx, ivf->s_in.ensure((size_t)B * ivf->d * 4));
+  HIPCHK(ctx, ivf->s_out_ids.ensure((size_t)B * k * 8));
+  HIPCHK(ctx, ivf->s_out_dist.ensure((size_t)B * k * 4));
+  HIPCHK(ctx, ivf->s_out_cnt.ensure((size_t)B * 4));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->s_in.p, q, (size_t)B * ivf->d * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = search_common(ivf, ivf->s_in.as<float>(), B, k, nprobe, all, ivf->s_out_ids.as<uint64_t>(),
+                     ivf->s_out_dist.as<float>(), ivf->s_out_cnt.as<uint32_t>(), nullptr);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(out_ids, ivf->s_out_ids.p, (size_t)B * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out_dist, ivf->s_out_dist.p, (size_t)B * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_counts)
+    HIPCHK(ctx, hipMemcpyAsync(out_counts, ivf->s_out_cnt.p, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+
+int fvdb_ivf_search(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t k, uint32_t nprobe, uint64_t* out_ids,
+                    float* out_dist, uint32_t* out_counts) {
+  return search_host(ivf, q, B, k, nprobe, false, out_ids, out_dist, out_counts);
+}
+int fvdb_ivf_search_all(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t k, uint64_t* out_ids, float* out_dist,
+                        uint32_t* out_counts) {
+  return search_host(ivf, q, B, k, 0, true, out_ids, out_dist, out_counts);
+}
+
+int fvdb_ivf_coarse(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t nprobe, uint32_t* out_clusters,
+                    float* out_dist) {
+  fvdb_ctx* ctx = ivf->ctx;
+  if (!ivf->trained) FAIL(ctx, FVDB_E_NOT_TRAINED, "index not trained");
+  if (B == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const uint32_t np = std::min(nprobe, ivf->nlist);
+  if (np == 0 || np > FVDB_MAX_K) FAIL(ctx, FVDB_E_UNSUPPORTED, "nprobe must be in 1..FVDB_MAX_K");
+  int rc = check_finite(ctx, q, (uint64_t)B * ivf->d);
+  if (rc) return rc;
+  HIPCHK(ctx, ivf->s_in.ensure((size_t)B * ivf->d * 4));
+  HIPCHK(ctx, ivf->s_probes.ensure((size_t)B * np * 4));
+  HIPCHK(ctx, ivf->s_cdist.ensure((size_t)B * np * 4));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->s_in.p, q, (size_t)B * ivf->d * 4, hipMemcpyHostToDevice, ctx->stream));
+  const float* qpad = nullptr;
+  rc = padded_queries(ivf, ivf->s_in.as<float>(), B, &qpad);
+  if (rc) return rc;
+  rc = run_coarse(ivf, qpad, B, np, ivf->s_probes.as<uint32_t>(), ivf->s_cdist.as<float>());
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(out_clusters, ivf->s_probes.p, (size_t)B * np * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_dist)
+    HIPCHK(ctx, hipMemcpyAsync(out_dist, ivf->s_cdist.p, (size_t)B * np * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+
+int fvdb_ivf_last_stats(fvdb_ivf* ivf, fvdb_search_stats* out) {
+  fvdb_ctx* ctx = ivf->ctx;
+  if (!ivf->s_scalars.p) {
+    std::memset(out, 0, sizeof(*out));
+    return FVDB_OK;
+  }
+  unsigned long long st[3];
+  HIPCHK(ctx, hipMemcpyAsync(st, ivf->s_scalars.as<uint32_t>() + 4, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  out->rows_scanned = st[0];
+  out->work_items = st[1];
+  out->list_rows_touched = st[2];
+  return FVDB_OK;
+}
+
+// stage times accumulated while profiling is on: ms[5] = coarse scan, coarse merge, plan, fine scan,
+// fine merge; returns the number of searches accumulated and resets.
+uint64_t fvdb_ivf_stage_times(fvdb_ivf* ivf, float* ms_out) {
+  for (int i = 0; i < 5; ++i) {
+    ms_out[i] = ivf->stage_ms[i];
+    ivf->stage_ms[i] = 0;
+  }
+  const uint64_t c = ivf->stage_calls;
+  ivf->stage_calls = 0;
+  return c;
+}
+
+// =============================================================================================
+// k-means training on the GPU (src/ivf/core.rs:240-429)
+// =============================================================================================
+int fvdb_ivf_train(fvdb_ivf* ivf, const float* x, uint64_t n, uint32_t max_iterations, uint64_t seed,
+                   fvdb_train_result* out) {
+  fvdb_ctx* ctx = ivf->ctx;
+  const uint32_t nlist = ivf->nlist, d = ivf->d;
+  if (n == 0 || n < nlist) FAIL(ctx, FVDB_E_INSUFFICIENT, "insufficient training data");
+  if (max_iterations == 0) FAIL(ctx, FVDB_E_INVALID, "max_iterations must be > 0");
+  if (d > 2048) FAIL(ctx, FVDB_E_UNSUPPORTED, "training supports d <= 2048");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = check_finite(ctx, x, n * d);
+  if (rc) return rc;
+  DBuf dx, dmind, dassign, dnew, ddist, dsc;
+  auto cleanup = [&]() {
+    dx.release(); dmind.release(); dassign.release(); dnew.release(); ddist.release(); dsc.release();
+  };
+#define TCHK(call)                                                        \
+  do {                                                                    \
+    hipError_t e_ = (call);                                               \
+    if (e_ != hipSuccess) {                                               \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);       \
+      cleanup();                                                          \
+      return e_ == hipErrorOutOfMemory ? FVDB_E_OOM : FVDB_E_HIP;         \
+    }                                                                     \
+  } while (0)
+  TCHK(dx.ensure(n * d * 4));
+  TCHK(dmind.ensure(n * 4));
+  TCHK(dassign.ensure(n * 4));
+  TCHK(dnew.ensure(n * 4));
+  TCHK(ddist.ensure(n * 4));
+  TCHK(dsc.ensure(64));
+  TCHK(ivf->d_centroids_rm.ensure((size_t)nlist * d * 4));
+  TCHK(hipMemcpyAsync(dx.p, x, n * d * 4, hipMemcpyHostToDevice, ctx->stream));
+  float* cent = ivf->d_centroids_rm.as<float>();
+  const uint32_t gn = cdiv(n, 256);
+
+  // ---- k-means++ seeding (:336-371); draws from SplitMix64(seed) ----
+  struct {
+    uint64_t s;
+    uint64_t next() {
+      uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      return z ^ (z >> 31);
+    }
+  } rng{seed};
+  uint64_t pick = rng.next() % n;
+  TCHK(hipMemcpyAsync(cent, dx.as<float>() + pick * d, (size_t)d * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(gn), dim3(256), 0, ctx->stream, dmind.as<float>(), n,
+                     __builtin_huge_valf());
+  uint32_t chosen = 1;
+  for (uint32_t i = 1; i < nlist; ++i) {
+    hipLaunchKernelGGL(kpp_min_dist_kernel, dim3(gn), dim3(256), 0, ctx->stream, dx.as<float>(), d, n, pick,
+                       dmind.as<float>());
+    const float u = (float)(rng.next() >> 40) * (1.0f / 16777216.0f);
+    hipLaunchKernelGGL(kpp_pick_kernel, dim3(1), dim3(64), 0, ctx->stream, dmind.as<float>(), n, u,
+                       (unsigned long long*)dsc.p);
+    unsigned long long p = 0;
+    TCHK(hipMemcpyAsync(&p, dsc.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TCHK(hipStreamSynchronize(ctx->stream));
+    if (p == ~0ull) continue;  // reference: the loop never fired, no centroid pushed this round
+    pick = p;
+    TCHK(hipMemcpyAsync(cent + (size_t)chosen * d, dx.as<float>() + pick * d, (size_t)d * 4,
+                        hipMemcpyDeviceToDevice, ctx->stream));
+    chosen++;
+  }
+  if (chosen < nlist) {
+    cleanup();
+    FAIL(ctx, FVDB_E_INVALID, "k-means++ produced fewer centroids than n_clusters (degenerate data)");
+  }
+
+  auto error_of = [&](float* out_err) -> int {
+    hipLaunchKernelGGL(kmeans_point_dist_kernel, dim3(gn), dim3(256), 0, ctx->stream, dx.as<float>(), d, n,
+                       dassign.as<uint32_t>(), cent, ddist.as<float>());
+    hipLaunchKernelGGL(seq_sqsum_mean_kernel, dim3(1), dim3(64), 0, ctx->stream, ddist.as<float>(), n,
+                       (float*)dsc.p + 4);
+    float r[2];
+    HIPCHK(ctx, hipMemcpyAsync(r, (float*)dsc.p + 4, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out_err = r[0];
+    return FVDB_OK;
+  };
+
+  TCHK(hipMemsetAsync(dassign.p, 0, n * 4, ctx->stream));  // assignments start at ClusterId(0) (:280)
+  float prev_error = __builtin_huge_valf(), initial_error = 0, final_error = 0;
+  rc = error_of(&initial_error);
+  if (rc) { cleanup(); return rc; }
+  bool converged = false;
+  uint32_t iterations = 0;
+  for (uint32_t iter = 0; iter < max_iterations; ++iter) {
+    iterations = iter + 1;
+    rc = install_centroids(ivf, cent);
+    if (rc) { cleanup(); return rc; }
+    rc = assign_dev(ivf, dx.as<float>(), n, dnew.as<uint32_t>());
+    if (rc) { cleanup(); return rc; }
+    TCHK(hipMemsetAsync(dsc.p, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(count_changed_kernel, dim3(gn), dim3(256), 0, ctx->stream, dnew.as<uint32_t>(),
+                       dassign.as<uint32_t>(), n, (uint32_t*)dsc.p);
+    uint32_t changed = 0;
+    TCHK(hipMemcpyAsync(&changed, dsc.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3(nlist), dim3(256), 0, ctx->stream, dx.as<float>(), d, n,
+                       dassign.as<uint32_t>(), cent);
+    TCHK(hipStreamSynchronize(ctx->stream));
+    if (iterations >= max_iterations) break;
+    float cur = 0;
+    rc = error_of(&cur);
+    if (rc) { cleanup(); return rc; }
+    const float change = std::fabs(prev_error - cur) / prev_error;
+    if (changed == 0 || change < 1e-4f) {
+      converged = true;
+      if (max_iterations == 10 && n < 20) {  // reference's small-test special case (:313-317)
+        prev_error = cur;
+        continue;
+      }
+      break;
+    }
+    prev_error = cur;
+  }
+  rc = error_of(&final_error);
+  if (rc) { cleanup(); return rc; }
+  ivf->h_centroids.resize((size_t)nlist * d);
+  TCHK(hipMemcpyAsync(ivf->h_centroids.data(), cent, (size_t)nlist * d * 4, hipMemcpyDeviceToHost, ctx->stream));
+  TCHK(hipStreamSynchronize(ctx->stream));
+  rc = install_centroids(ivf, cent);
+  cleanup();
+  if (rc) return rc;
+  reset_lists(ivf);
+  if (ivf->pool.valid && ivf->pool.cap_blocks)
+    HIPCHK(ctx, hipMemsetAsync(ivf->pool.valid, 0, (size_t)ivf->pool.cap_blocks * 8, ctx->stream));
+  if (out) {
+    out->iterations = iterations;
+    out->converged = converged ? 1 : 0;
+    out->initial_error = initial_error;
+    out->final_error = final_error;
+  }
+#undef TCHK
+  return FVDB_OK;
+}
+
+// =============================================================================================
+// merge of per-shard partial results
+// =============================================================================================
+int fvdb_merge_keys_dev(fvdb_ctx* ctx, const uint64_t* keys, const uint64_t* ids, uint32_t G, uint32_t B, uint32_t k,
+                        uint64_t* out_ids, float* out_dist, uint32_t* out_counts) {
+  if (k == 0 || k > FVDB_MAX_K) FAIL(ctx, FVDB_E_UNSUPPORTED, "k must be in 1..FVDB_MAX_K");
+  if (B == 0 || G == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const uint32_t grid = cdiv(B, 4);
+  switch (kr_for(k)) {
+    case 1: hipLaunchKernelGGL((merge_keys_kernel<1>), dim3(grid), dim3(256), 0, ctx->stream, keys, ids, G, B, k, out_ids, out_dist, out_counts); break;
+    case 2: hipLaunchKernelGGL((merge_keys_kernel<2>), dim3(grid), dim3(256), 0, ctx->stream, keys, ids, G, B, k, out_ids, out_dist, out_counts); break;
+    default: hipLaunchKernelGGL((merge_keys_kernel<4>), dim3(grid), dim3(256), 0, ctx->stream, keys, ids, G, B, k, out_ids, out_dist, out_counts); break;
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return FVDB_OK;
+}
+
+// =============================================================================================
+// row store + candidate scoring
+// =============================================================================================
+int fvdb_store_create(fvdb_ctx* ctx, uint32_t d, uint64_t capacity_rows, fvdb_store** out) {
+  if (!ctx || !out) return FVDB_E_INVALID;
+  *out = nullptr;
+  if (d == 0) FAIL(ctx, FVDB_E_INVALID, "d must be > 0");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  fvdb_store* s = new (std::nothrow) fvdb_store();
+  if (!s) return FVDB_E_OOM;
+  s->ctx = ctx;
+  s->d = d;
+  s->dpad = ((d + 3) / 4) * 4;
+  s->cap = std::max<uint64_t>(capacity_rows, 64);
+  hipError_t e = hipMalloc(&s->data, s->cap * s->dpad * 4);
+  if (e != hipSuccess) {
+    delete s;
+    FAIL(ctx, FVDB_E_OOM, "store allocation failed");
+  }
+  *out = s;
+  return FVDB_OK;
+}
+
+void fvdb_store_destroy(fvdb_store* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->ctx->device);
+  (void)hipStreamSynchronize(s->ctx->stream);
+  if (s->data) (void)hipFree(s->data);
+  s->s_q.release();
+  s->s_cand.release();
+  s->s_out.release();
+  s->s_in.release();
+  delete s;
+}
+
+uint64_t fvdb_store_rows(fvdb_store* s) { return s->rows; }
+
+int fvdb_store_append(fvdb_store* s, const float* rows, uint64_t n, uint64_t* first_row) {
+  fvdb_ctx* ctx = s->ctx;
+  if (first_row) *first_row = s->rows;
+  if (n == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = check_finite(ctx, rows, n * s->d);
+  if (rc) return rc;
+  if (s->rows + n >= 0xFFFFFFFFull) FAIL(ctx, FVDB_E_UNSUPPORTED, "store limited to 2^32-1 rows");
+  if (s->rows + n > s->cap) {
+    uint64_t ncap = std::max<uint64_t>(s->rows + n, s->cap + s->cap / 2);
+    float* nd = nullptr;
+    HIPCHK(ctx, hipMalloc(&nd, ncap * s->dpad * 4));
+    if (s->rows)
+      HIPCHK(ctx, hipMemcpyAsync(nd, s->data, s->rows * s->dpad * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(s->data);
+    s->data = nd;
+    s->cap = ncap;
+  }
+  float* dst = s->data + s->rows * s->dpad;
+  if (s->d == s->dpad) {
+    HIPCHK(ctx, hipMemcpyAsync(dst, rows, n * s->d * 4, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    HIPCHK(ctx, s->s_in.ensure(n * s->d * 4));
+    HIPCHK(ctx, hipMemcpyAsync(s->s_in.p, rows, n * s->d * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv(n * s->dpad, 256)), dim3(256), 0, ctx->stream, s->s_in.as<float>(),
+                       s->d, s->dpad, n, dst);
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  s->rows += n;
+  return FVDB_OK;
+}
+
+int fvdb_store_get(fvdb_store* s, uint64_t row, float* out) {
+  fvdb_ctx* ctx = s->ctx;
+  if (row >= s->rows) FAIL(ctx, FVDB_E_NOT_FOUND, "row out of range");
+  HIPCHK(ctx, hipMemcpyAsync(out, s->data + row * s->dpad, (size_t)s->d * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+
+int fvdb_score_candidates(fvdb_store* s, const float* q, uint32_t B, const uint32_t* cand, uint32_t C, float* out) {
+  fvdb_ctx* ctx = s->ctx;
+  if (B == 0 || C == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = check_finite(ctx, q, (uint64_t)B * s->d);
+  if (rc) return rc;
+  for (uint64_t i = 0; i < (uint64_t)B * C; ++i)
+    if (cand[i] != FVDB_NO_ROW && cand[i] >= s->rows) FAIL(ctx, FVDB_E_NOT_FOUND, "candidate row out of range");
+  HIPCHK(ctx, s->s_in.ensure((size_t)B * s->d * 4));
+  HIPCHK(ctx, s->s_q.ensure((size_t)B * s->dpad * 4));
+  HIPCHK(ctx, s->s_cand.ensure((size_t)B * C * 4));
+  HIPCHK(ctx, s->s_out.ensure((size_t)B * C * 4));
+  const float* qd = nullptr;
+  if (s->d == s->dpad) {
+    HIPCHK(ctx, hipMemcpyAsync(s->s_q.p, q, (size_t)B * s->d * 4, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    HIPCHK(ctx, hipMemcpyAsync(s->s_in.p, q, (size_t)B * s->d * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv((uint64_t)B * s->dpad, 256)), dim3(256), 0, ctx->stream,
+                       s->s_in.as<float>(), s->d, s->dpad, (uint64_t)B, s->s_q.as<float>());
+  }
+  qd = s->s_q.as<float>();
+  HIPCHK(ctx, hipMemcpyAsync(s->s_cand.p, cand, (size_t)B * C * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(score_candidates_kernel, dim3(cdiv((uint64_t)B * C, 256)), dim3(256), 0, ctx->stream, s->data,
+                     s->dpad, qd, s->s_cand.as<uint32_t>(), B, C, C, s->s_out.as<float>());
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out, s->s_out.p, (size_t)B * C * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+
+int fvdb_scorer_create(fvdb_store* s, uint32_t max_B, uint32_t max_C, fvdb_scorer** out) {
+  fvdb_ctx* ctx = s->ctx;
+  if (!out || max_B == 0 || max_C == 0) FAIL(ctx, FVDB_E_INVALID, "bad scorer shape");
+  *out = nullptr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  fvdb_scorer* sc = new (std::nothrow) fvdb_scorer();
+  if (!sc) return FVDB_E_OOM;
+  sc->store = s;
+  sc->max_B = max_B;
+  sc->max_C = max_C;
+  const size_t nc = (size_t)max_B * max_C;
+  if (hipMalloc(&sc->d_q, (size_t)max_B * s->dpad * 4) != hipSuccess ||
+      hipHostMalloc((void**)&sc->h_cand, nc * 4, hipHostMallocMapped) != hipSuccess ||
+      hipHostMalloc((void**)&sc->h_dist, nc * 4, hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&sc->d_cand, sc->h_cand, 0) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&sc->d_dist, sc->h_dist, 0) != hipSuccess) {
+    fvdb_scorer_destroy(sc);
+    FAIL(ctx, FVDB_E_OOM, "scorer allocation failed");
+  }
+  std::memset(sc->h_cand, 0xFF, nc * 4);
+  *out = sc;
+  return FVDB_OK;
+}
+
+void fvdb_scorer_destroy(fvdb_scorer* sc) {
+  if (!sc) return;
+  (void)hipSetDevice(sc->store->ctx->device);
+  (void)hipStreamSynchronize(sc->store->ctx->stream);
+  if (sc->d_q) (void)hipFree(sc->d_q);
+  if (sc->h_cand) (void)hipHostFree(sc->h_cand);
+  if (sc->h_dist) (void)hipHostFree(sc->h_dist);
+  sc->s_rows.release();
+  delete sc;
+}
+
+int fvdb_scorer_set_queries(fvdb_scorer* sc, const float* q, uint32_t B) {
+  fvdb_store* s = sc->store;
+  fvdb_ctx* ctx = s->ctx;
+  if (B > sc->max_B) FAIL(ctx, FVDB_E_INVALID, "B above scorer capacity");
+  if (B == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = check_finite(ctx, q, (uint64_t)B * s->d);
+  if (rc) return rc;
+  if (s->d == s->dpad) {
+    HIPCHK(ctx, hipMemcpyAsync(sc->d_q, q, (size_t)B * s->d * 4, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    HIPCHK(ctx, s->s_in.ensure((size_t)B * s->d * 4));
+    HIPCHK(ctx, hipMemcpyAsync(s->s_in.p, q, (size_t)B * s->d * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv((uint64_t)B * s->dpad, 256)), dim3(256), 0, ctx->stream,
+                       s->s_in.as<float>(), s->d, s->dpad, (uint64_t)B, sc->d_q);
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+
+int fvdb_scorer_set_query_rows(fvdb_scorer* sc, const uint32_t* rows, uint32_t B) {
+  fvdb_store* s = sc->store;
+  fvdb_ctx* ctx = s->ctx;
+  if (B > sc->max_B) FAIL(ctx, FVDB_E_INVALID, "B above scorer capacity");
+  if (B == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  for (uint32_t i = 0; i < B; ++i)
+    if (rows[i] >= s->rows) FAIL(ctx, FVDB_E_NOT_FOUND, "query row out of range");
+  HIPCHK(ctx, sc->s_rows.ensure((size_t)B * 4));
+  HIPCHK(ctx, hipMemcpyAsync(sc->s_rows.p, rows, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv((uint64_t)B * s->dpad, 256)), dim3(256), 0, ctx->stream, s->data,
+                     sc->s_rows.as<uint32_t>(), s->dpad, B, sc->d_q);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+
+uint32_t* fvdb_scorer_cand_buffer(fvdb_scorer* sc) { return sc->h_cand; }
+const float* fvdb_scorer_dist_buffer(fvdb_scorer* sc) { return sc->h_dist; }
+
+int fvdb_scorer_run(fvdb_scorer* sc, uint32_t B, uint32_t C) {
+  fvdb_store* s = sc->store;
+  fvdb_ctx* ctx = s->ctx;
+  if (B > sc->max_B || C > sc->max_C) FAIL(ctx, FVDB_E_INVALID, "shape above scorer capacity");
+  if (B == 0 || C == 0) return FVDB_OK;
+  hipLaunchKernelGGL(score_candidates_kernel, dim3(cdiv((uint64_t)B * C, 256)), dim3(256), 0, ctx->stream, s->data,
+                     s->dpad, sc->d_q, sc->d_cand, B, C, sc->max_C, sc->d_dist);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+
+}  // extern "C"

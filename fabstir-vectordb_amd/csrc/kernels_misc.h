@@ -1,0 +1,196 @@
+// kernels_misc.h — layout conversion, candidate scoring (HNSW hops) and k-means reductions.
+#pragma once
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace fvdb {
+
+// Row-major [n][d] (device) -> blocked pool slots.  One thread per (row, 4-dim chunk).
+__global__ void scatter_rows_kernel(const float* __restrict__ src, uint32_t d, uint32_t d4, uint64_t n,
+                                    const uint32_t* __restrict__ dst_slot, const uint64_t* __restrict__ row_ids,
+                                    float4* __restrict__ pool_data, uint64_t* __restrict__ pool_ids,
+                                    unsigned long long* __restrict__ pool_valid) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t i = t / d4;
+  const uint32_t c = (uint32_t)(t % d4);
+  if (i >= n) return;
+  const uint32_t slot = dst_slot[i];
+  const uint32_t blk = slot >> 6, lane = slot & 63;
+  const float* r = src + i * d + 4 * c;
+  float4 v;
+  v.x = (4 * c + 0 < d) ? r[0] : 0.0f;
+  v.y = (4 * c + 1 < d) ? r[1] : 0.0f;
+  v.z = (4 * c + 2 < d) ? r[2] : 0.0f;
+  v.w = (4 * c + 3 < d) ? r[3] : 0.0f;
+  pool_data[((size_t)blk * d4 + c) * 64 + lane] = v;
+  if (c == 0) {
+    pool_ids[(size_t)blk * 64 + lane] = row_ids ? row_ids[i] : i;
+    atomicOr(pool_valid + blk, 1ull << lane);
+  }
+}
+
+// Soft delete / undelete: slots = block*64 + lane.
+__global__ void set_valid_kernel(const uint32_t* __restrict__ slots, uint64_t n, int deleted,
+                                 unsigned long long* __restrict__ pool_valid) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t blk = slots[i] >> 6, lane = slots[i] & 63;
+  if (deleted)
+    atomicAnd(pool_valid + blk, ~(1ull << lane));
+  else
+    atomicOr(pool_valid + blk, 1ull << lane);
+}
+
+// [n][d] -> [n][dpad] zero padded (queries whose d is not a multiple of 4; store rows).
+__global__ void pad_rows_kernel(const float* __restrict__ src, uint32_t d, uint32_t dpad, uint64_t n,
+                                float* __restrict__ dst) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * dpad) return;
+  const uint64_t i = t / dpad;
+  const uint32_t j = (uint32_t)(t % dpad);
+  dst[t] = j < d ? src[i * d + j] : 0.0f;
+}
+
+// queries[b] = rows[idx[b]] (both [.][dpad])
+__global__ void gather_rows_kernel(const float* __restrict__ rows, const uint32_t* __restrict__ idx, uint32_t dpad,
+                                   uint32_t B, float* __restrict__ dst) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (uint64_t)B * dpad) return;
+  const uint32_t b = (uint32_t)(t / dpad), j = (uint32_t)(t % dpad);
+  dst[t] = rows[(size_t)idx[b] * dpad + j];
+}
+
+// Candidate scoring for graph hops: lane = one (query, candidate) pair, sequential f32 fold like
+// src/hnsw/core.rs:691-697.  cand may live in pinned host memory mapped into the GPU.
+__global__ __launch_bounds__(256) void score_candidates_kernel(const float* __restrict__ rows, uint32_t dpad,
+                                                               const float* __restrict__ queries,
+                                                               const uint32_t* __restrict__ cand, uint32_t B,
+                                                               uint32_t C, uint32_t stride, float* __restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * C) return;
+  const uint32_t b = t / C, c = t - b * C;
+  const uint32_t row = cand[(size_t)b * stride + c];
+  float res = __uint_as_float(0x7F800000u);
+  if (row != 0xFFFFFFFFu) {
+    const float4* xp = (const float4*)(rows + (size_t)row * dpad);
+    const float4* qp = (const float4*)(queries + (size_t)b * dpad);
+    float acc = 0.0f;
+    for (uint32_t i = 0; i < dpad / 4; ++i) {
+      const float4 x = xp[i], q = qp[i];
+      float u;
+      u = q.x - x.x; acc = acc + u * u;
+      u = q.y - x.y; acc = acc + u * u;
+      u = q.z - x.z; acc = acc + u * u;
+      u = q.w - x.w; acc = acc + u * u;
+    }
+    res = sqrtf(acc);
+  }
+  out[(size_t)b * stride + c] = res;
+}
+
+// ---- k-means (src/ivf/core.rs:388-429): sums in data order, like the reference --------------
+// One block per cluster; thread t owns dims t, t+256, ...; every thread walks the assignment
+// array (wave-uniform branch) and adds member rows in data order.
+__global__ __launch_bounds__(256) void kmeans_update_kernel(const float* __restrict__ x, uint32_t d, uint64_t n,
+                                                            const uint32_t* __restrict__ assign,
+                                                            float* __restrict__ centroids /* [nlist][d] */) {
+  const uint32_t c = blockIdx.x;
+  constexpr int MAXD = 8;  // d <= 2048
+  float sum[MAXD];
+#pragma unroll
+  for (int s = 0; s < MAXD; ++s) sum[s] = 0.0f;
+  uint64_t count = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (assign[i] == c) {
+      ++count;
+#pragma unroll
+      for (int s = 0; s < MAXD; ++s) {
+        const uint32_t j = threadIdx.x + s * 256;
+        if (j < d) sum[s] += x[i * d + j];
+      }
+    }
+  }
+  if (count > 0) {
+#pragma unroll
+    for (int s = 0; s < MAXD; ++s) {
+      const uint32_t j = threadIdx.x + s * 256;
+      if (j < d) centroids[(size_t)c * d + j] = sum[s] / (float)count;
+    }
+  }
+}
+
+// dist[i] = L2(x_i, centroid[assign_i]) (sequential fold per lane)
+__global__ void kmeans_point_dist_kernel(const float* __restrict__ x, uint32_t d, uint64_t n,
+                                         const uint32_t* __restrict__ assign, const float* __restrict__ centroids,
+                                         float* __restrict__ dist) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* a = x + i * d;
+  const float* b = centroids + (size_t)assign[i] * d;
+  float acc = 0.0f;
+  for (uint32_t j = 0; j < d; ++j) {
+    const float t = a[j] - b[j];
+    acc = acc + t * t;
+  }
+  dist[i] = sqrtf(acc);
+}
+
+// total = sum_i dist_i*dist_i in index order (one lane; n adds), out = total / n
+__global__ void seq_sqsum_mean_kernel(const float* __restrict__ dist, uint64_t n, float* __restrict__ out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float total = 0.0f;
+    for (uint64_t i = 0; i < n; ++i) total += dist[i] * dist[i];
+    out[0] = total / (float)n;
+    out[1] = total;
+  }
+}
+
+// k-means++ helpers (src/ivf/core.rs:336-371)
+// mind[j] = min(mind[j], L2(x_j, x_pick))
+__global__ void kpp_min_dist_kernel(const float* __restrict__ x, uint32_t d, uint64_t n, uint64_t pick,
+                                    float* __restrict__ mind) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* a = x + i * d;
+  const float* b = x + pick * d;
+  float acc = 0.0f;
+  for (uint32_t j = 0; j < d; ++j) {
+    const float t = a[j] - b[j];
+    acc = acc + t * t;
+  }
+  mind[i] = fminf(mind[i], sqrtf(acc));
+}
+// sequential: total = sum d^2; threshold = u * total; first j with cumulative >= threshold
+__global__ void kpp_pick_kernel(const float* __restrict__ mind, uint64_t n, float u, unsigned long long* out_pick) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float total = 0.0f;
+    for (uint64_t j = 0; j < n; ++j) total += mind[j] * mind[j];
+    const float threshold = u * total;
+    float cumulative = 0.0f;
+    unsigned long long pick = ~0ull;
+    for (uint64_t j = 0; j < n; ++j) {
+      cumulative += mind[j] * mind[j];
+      if (cumulative >= threshold) {
+        pick = j;
+        break;
+      }
+    }
+    *out_pick = pick;
+  }
+}
+__global__ void fill_f32_kernel(float* p, uint64_t n, float v) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void count_changed_kernel(const uint32_t* __restrict__ a, uint32_t* __restrict__ b, uint64_t n,
+                                     uint32_t* __restrict__ changed) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (a[i] != b[i]) {
+    b[i] = a[i];
+    atomicAdd(changed, 1u);
+  }
+}
+
+}  // namespace fvdb

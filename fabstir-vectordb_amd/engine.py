@@ -1,0 +1,328 @@
+"""Thin Python view of the C ABI (include/fvdb.h): handles, numpy marshalling, errors.
+
+Error classes follow the reference's enums (IVFError / HNSWError / HybridError,
+src/ivf/core.rs:14-39, src/hnsw/core.rs, src/hybrid/core.rs).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import f32p, u32p, u64p
+
+
+class FvdbError(Exception):
+    status = None
+
+
+class NotTrained(FvdbError):
+    pass
+
+
+class DuplicateVector(FvdbError):
+    pass
+
+
+class DimensionMismatch(FvdbError):
+    pass
+
+
+class InsufficientTrainingData(FvdbError):
+    pass
+
+
+class InconsistentDimensions(FvdbError):
+    pass
+
+
+class InvalidConfig(FvdbError):
+    pass
+
+
+class VectorNotFound(FvdbError):
+    pass
+
+
+class NotInitialized(FvdbError):
+    pass
+
+
+class NonFiniteInput(FvdbError):
+    pass
+
+
+class HipError(FvdbError):
+    pass
+
+
+class OutOfMemory(FvdbError):
+    pass
+
+
+class Unsupported(FvdbError):
+    pass
+
+
+STATUS_TO_EXC = {1: NotTrained, 2: DuplicateVector, 3: DimensionMismatch, 4: InsufficientTrainingData,
+                 5: InconsistentDimensions, 6: InvalidConfig, 7: VectorNotFound, 8: NotInitialized,
+                 9: NonFiniteInput, 10: HipError, 11: OutOfMemory, 12: Unsupported}
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+class Context:
+    """One GPU + one HIP stream (fvdb_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = _capi.load()
+        h = C.c_void_p()
+        rc = self.lib.fvdb_ctx_create(device, C.byref(h))
+        if rc:
+            raise STATUS_TO_EXC.get(rc, FvdbError)(f"fvdb_ctx_create(device={device}) failed with status {rc}")
+        self.h = h
+        self.device = device
+
+    def check(self, rc):
+        if rc:
+            msg = self.lib.fvdb_last_error(self.h)
+            exc = STATUS_TO_EXC.get(rc, FvdbError)(msg.decode() if msg else f"status {rc}")
+            exc.status = rc
+            raise exc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fvdb_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self.check(self.lib.fvdb_ctx_synchronize(self.h))
+
+    def set_profiling(self, on):
+        self.check(self.lib.fvdb_ctx_set_profiling(self.h, int(on)))
+
+    # --- raw device buffers (bench keeps its inputs resident in HBM) ---
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(self.lib.fvdb_dev_alloc(self.h, nbytes, C.byref(p)))
+        return p
+
+    def free(self, p):
+        self.check(self.lib.fvdb_dev_free(self.h, p))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.alloc(arr.nbytes)
+        self.check(self.lib.fvdb_dev_upload(self.h, p, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        return p
+
+    def download(self, p, shape, dtype):
+        out = np.empty(shape, dtype)
+        self.check(self.lib.fvdb_dev_download(self.h, out.ctypes.data_as(C.c_void_p), p, out.nbytes))
+        return out
+
+    def timer_start(self):
+        self.check(self.lib.fvdb_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float(0)
+        self.check(self.lib.fvdb_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+
+class DeviceIVF:
+    """IVF-flat index resident in HBM (fvdb_ivf): centroids + paged inverted lists."""
+
+    def __init__(self, ctx, d, nlist):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.d, self.nlist = int(d), int(nlist)
+        h = C.c_void_p()
+        ctx.check(self.lib.fvdb_ivf_create(ctx.h, self.d, self.nlist, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.lib.fvdb_ivf_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _rows(self, x):
+        x = _f32(x)
+        if x.ndim == 1:
+            x = x.reshape(1, -1)
+        if x.shape[1] != self.d:
+            raise DimensionMismatch(f"Dimension mismatch: expected {self.d}, got {x.shape[1]}")
+        return x
+
+    def set_centroids(self, centroids):
+        c = self._rows(centroids)
+        if c.shape[0] != self.nlist:
+            raise InvalidConfig(f"expected {self.nlist} centroids, got {c.shape[0]}")
+        self.ctx.check(self.lib.fvdb_ivf_set_centroids(self.h, _ptr(c, f32p)))
+
+    def get_centroids(self):
+        out = np.empty((self.nlist, self.d), np.float32)
+        self.ctx.check(self.lib.fvdb_ivf_get_centroids(self.h, _ptr(out, f32p)))
+        return out
+
+    def train(self, x, max_iterations=25, seed=0):
+        x = self._rows(x)
+        res = _capi.TrainResult()
+        self.ctx.check(self.lib.fvdb_ivf_train(self.h, _ptr(x, f32p), x.shape[0], max_iterations, seed, C.byref(res)))
+        return dict(iterations=res.iterations, converged=bool(res.converged), initial_error=res.initial_error,
+                    final_error=res.final_error)
+
+    def assign(self, x):
+        x = self._rows(x)
+        out = np.empty(x.shape[0], np.uint32)
+        self.ctx.check(self.lib.fvdb_ivf_assign(self.h, _ptr(x, f32p), x.shape[0], _ptr(out, u32p)))
+        return out
+
+    def add(self, x, ids):
+        x = self._rows(x)
+        ids = np.ascontiguousarray(ids, np.uint64)
+        cl = np.empty(x.shape[0], np.uint32)
+        pos = np.empty(x.shape[0], np.uint32)
+        self.ctx.check(self.lib.fvdb_ivf_add(self.h, _ptr(x, f32p), _ptr(ids, u64p), x.shape[0], _ptr(cl, u32p),
+                                             _ptr(pos, u32p)))
+        return cl, pos
+
+    def add_assigned(self, x, ids, clusters):
+        x = self._rows(x)
+        ids = np.ascontiguousarray(ids, np.uint64)
+        cl = np.ascontiguousarray(clusters, np.uint32)
+        pos = np.empty(x.shape[0], np.uint32)
+        self.ctx.check(self.lib.fvdb_ivf_add_assigned(self.h, _ptr(x, f32p), _ptr(ids, u64p), x.shape[0],
+                                                      _ptr(cl, u32p), _ptr(pos, u32p)))
+        return pos
+
+    def set_deleted(self, clusters, pos, deleted=True):
+        cl = np.ascontiguousarray(clusters, np.uint32)
+        ps = np.ascontiguousarray(pos, np.uint32)
+        self.ctx.check(self.lib.fvdb_ivf_set_deleted(self.h, _ptr(cl, u32p), _ptr(ps, u32p), cl.size, int(deleted)))
+
+    def list_sizes(self):
+        out = np.empty(self.nlist, np.uint64)
+        self.ctx.check(self.lib.fvdb_ivf_list_sizes(self.h, _ptr(out, u64p)))
+        return out
+
+    def total_rows(self):
+        return int(self.lib.fvdb_ivf_total_rows(self.h))
+
+    def reserve(self, n_rows):
+        self.ctx.check(self.lib.fvdb_ivf_reserve(self.h, n_rows))
+
+    def clear(self):
+        self.ctx.check(self.lib.fvdb_ivf_clear(self.h))
+
+    def set_global_list_sizes(self, sizes):
+        s = np.ascontiguousarray(sizes, np.uint64)
+        self.ctx.check(self.lib.fvdb_ivf_set_global_list_sizes(self.h, _ptr(s, u64p)))
+
+    def _out(self, B, k):
+        return (np.empty((B, k), np.uint64), np.empty((B, k), np.float32), np.empty(B, np.uint32))
+
+    def search(self, q, k, nprobe):
+        q = self._rows(q)
+        ids, ds, cnt = self._out(q.shape[0], k)
+        self.ctx.check(self.lib.fvdb_ivf_search(self.h, _ptr(q, f32p), q.shape[0], k, nprobe, _ptr(ids, u64p),
+                                                _ptr(ds, f32p), _ptr(cnt, u32p)))
+        return ids, ds, cnt
+
+    def search_all(self, q, k):
+        q = self._rows(q)
+        ids, ds, cnt = self._out(q.shape[0], k)
+        self.ctx.check(self.lib.fvdb_ivf_search_all(self.h, _ptr(q, f32p), q.shape[0], k, _ptr(ids, u64p),
+                                                    _ptr(ds, f32p), _ptr(cnt, u32p)))
+        return ids, ds, cnt
+
+    def search_dev(self, q_dev, B, k, nprobe, ids_dev, dist_dev, cnt_dev, keys_dev=None):
+        self.ctx.check(self.lib.fvdb_ivf_search_dev(self.h, q_dev, B, k, nprobe, ids_dev, dist_dev, cnt_dev, keys_dev))
+
+    def search_all_dev(self, q_dev, B, k, ids_dev, dist_dev, cnt_dev):
+        self.ctx.check(self.lib.fvdb_ivf_search_all_dev(self.h, q_dev, B, k, ids_dev, dist_dev, cnt_dev))
+
+    def coarse(self, q, nprobe):
+        q = self._rows(q)
+        npb = min(nprobe, self.nlist)
+        cl = np.empty((q.shape[0], npb), np.uint32)
+        ds = np.empty((q.shape[0], npb), np.float32)
+        self.ctx.check(self.lib.fvdb_ivf_coarse(self.h, _ptr(q, f32p), q.shape[0], nprobe, _ptr(cl, u32p), _ptr(ds, f32p)))
+        return cl, ds
+
+    def last_stats(self):
+        st = _capi.SearchStats()
+        self.ctx.check(self.lib.fvdb_ivf_last_stats(self.h, C.byref(st)))
+        return dict(rows_scanned=st.rows_scanned, work_items=st.work_items, list_rows_touched=st.list_rows_touched)
+
+    def stage_times(self):
+        ms = np.zeros(5, np.float32)
+        n = self.lib.fvdb_ivf_stage_times(self.h, _ptr(ms, f32p))
+        return int(n), dict(zip(("coarse_scan", "coarse_merge", "plan", "fine_scan", "fine_merge"), ms.tolist()))
+
+
+class RowStore:
+    """Row-major vector store for gathered candidate scoring (fvdb_store)."""
+
+    def __init__(self, ctx, d, capacity_rows=1024):
+        self.ctx, self.lib, self.d = ctx, ctx.lib, int(d)
+        h = C.c_void_p()
+        ctx.check(self.lib.fvdb_store_create(ctx.h, self.d, capacity_rows, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.lib.fvdb_store_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def append(self, rows):
+        r = _f32(rows)
+        if r.ndim == 1:
+            r = r.reshape(1, -1)
+        if r.shape[1] != self.d:
+            raise DimensionMismatch(f"Dimension mismatch: expected {self.d}, got {r.shape[1]}")
+        first = C.c_uint64(0)
+        self.ctx.check(self.lib.fvdb_store_append(self.h, _ptr(r, f32p), r.shape[0], C.byref(first)))
+        return first.value
+
+    def rows(self):
+        return int(self.lib.fvdb_store_rows(self.h))
+
+    def get(self, row):
+        out = np.empty(self.d, np.float32)
+        self.ctx.check(self.lib.fvdb_store_get(self.h, row, _ptr(out, f32p)))
+        return out
+
+    def score_candidates(self, q, cand):
+        q = _f32(q)
+        cand = np.ascontiguousarray(cand, np.uint32)
+        B, Cn = cand.shape
+        out = np.empty((B, Cn), np.float32)
+        self.ctx.check(self.lib.fvdb_score_candidates(self.h, _ptr(q, f32p), B, _ptr(cand, u32p), Cn, _ptr(out, f32p)))
+        return out
+
+
+def merge_keys_dev(ctx, keys_dev, ids_dev, G, B, k, out_ids_dev, out_dist_dev, out_cnt_dev):
+    ctx.check(ctx.lib.fvdb_merge_keys_dev(ctx.h, keys_dev, ids_dev, G, B, k, out_ids_dev, out_dist_dev, out_cnt_dev))

@@ -1,0 +1,185 @@
+/* fvdb.h — C ABI of the MI355X-native distance/top-k engine for fabstir-vectordb's
+ * hybrid HNSW/IVF hot path.
+ *
+ * The reference (Rust) has NO FFI seam for distance computation: the L2 loops are called
+ * directly (src/ivf/core.rs:351,378,424,650,671; src/hnsw/core.rs:279,434,487,515,573,605,611).
+ * This header DEFINES the seam exactly at those call sites; each entry point cites the
+ * reference code it replaces.  A Rust host binds it with a plain `extern "C"` block
+ * (see INTEGRATION.md); this repo's own host code (C++, fabstir-vectordb_amd/host) and the
+ * test harness (Python ctypes) use the same symbols.
+ *
+ * Conventions
+ *  - plain pointers + sizes, row-major, no strides; caller owns host buffers for the
+ *    duration of a call; the library owns device memory behind opaque handles.
+ *  - `*_dev` variants take DEVICE pointers (HBM-resident inputs/outputs) and only enqueue
+ *    work on the context's stream (call fvdb_ctx_synchronize or use the stream).
+ *  - every call returns an fvdb_status; nothing throws or aborts across the boundary.
+ *    Fewer than k hits is NOT an error (reference returns a short list:
+ *    tests/ivf/core.rs:385-398, tests/hnsw/core.rs:300-316): see out_counts.
+ *  - distances are the reference's arithmetic bit for bit: sqrt(sum_i (a_i-b_i)^2), f32,
+ *    summed left to right, no FMA (src/core/vector_ops.rs:51-57).
+ *  - ordering: ascending distance; exact ties keep scan order (probe rank, then position
+ *    in the list) = what the reference's stable sort gives (src/ivf/core.rs:655,677).
+ *  - threading: search entry points may be called concurrently on DIFFERENT contexts;
+ *    calls on one context are serialised by the caller (reference: tokio RwLock,
+ *    bindings/node/src/session.rs:253).  Mutations need external exclusion.
+ */
+#ifndef FVDB_H
+#define FVDB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum fvdb_status {
+  FVDB_OK = 0,
+  FVDB_E_NOT_TRAINED = 1,   /* IVFError::NotTrained            src/ivf/core.rs:16 */
+  FVDB_E_DUPLICATE = 2,     /* IVFError/HNSWError::DuplicateVector (raised by host code) */
+  FVDB_E_DIM = 3,           /* DimensionMismatch                src/ivf/core.rs:22 */
+  FVDB_E_INSUFFICIENT = 4,  /* InsufficientTrainingData         src/ivf/core.rs:25 */
+  FVDB_E_INCONSISTENT = 5,  /* InconsistentDimensions           src/ivf/core.rs:28 */
+  FVDB_E_INVALID = 6,       /* InvalidConfig / bad argument     src/ivf/core.rs:31 */
+  FVDB_E_NOT_FOUND = 7,     /* VectorNotFound                   src/ivf/core.rs:37 */
+  FVDB_E_NOT_INITIALIZED = 8, /* HybridError::NotInitialized    src/hybrid/core.rs */
+  FVDB_E_NONFINITE = 9,     /* NaN/Inf input (reference panics: partial_cmp().unwrap()) */
+  FVDB_E_HIP = 10,          /* HIP runtime error (message via fvdb_last_error) */
+  FVDB_E_OOM = 11,          /* device or host allocation failed */
+  FVDB_E_UNSUPPORTED = 12   /* k or nprobe above the compiled limit (FVDB_MAX_K) */
+} fvdb_status;
+
+/* Largest k (and nprobe) served by the in-kernel wavefront top-k (64 lanes x 4 registers). */
+#define FVDB_MAX_K 256u
+/* Row id meaning "no row" in padded outputs / candidate lists. */
+#define FVDB_NO_ROW UINT32_MAX
+#define FVDB_NO_ID UINT64_MAX
+
+typedef struct fvdb_ctx fvdb_ctx;     /* one GPU + one HIP stream + scratch arenas */
+typedef struct fvdb_ivf fvdb_ivf;     /* IVF-flat index resident in HBM (centroids + paged lists) */
+typedef struct fvdb_store fvdb_store; /* row-major vector store for gathered candidate scoring */
+
+/* ---- context ------------------------------------------------------------------------ */
+int fvdb_ctx_create(int device, fvdb_ctx** out);
+void fvdb_ctx_destroy(fvdb_ctx* ctx);
+int fvdb_ctx_synchronize(fvdb_ctx* ctx);
+void* fvdb_ctx_stream(fvdb_ctx* ctx);          /* hipStream_t, for callers that interleave work */
+const char* fvdb_last_error(fvdb_ctx* ctx);    /* message of the last failing call on ctx */
+const char* fvdb_version(void);
+/* Device memory helpers so a host without a HIP binding can keep inputs resident in HBM. */
+int fvdb_dev_alloc(fvdb_ctx* ctx, size_t bytes, void** out);
+int fvdb_dev_free(fvdb_ctx* ctx, void* p);
+int fvdb_dev_upload(fvdb_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int fvdb_dev_download(fvdb_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* Stream-ordered timing of the region between the two calls (HIP events on ctx's stream). */
+int fvdb_timer_start(fvdb_ctx* ctx);
+int fvdb_timer_stop_ms(fvdb_ctx* ctx, float* out_ms);
+/* Per-stage HIP-event timing of searches on this context (adds one stream sync per search). */
+int fvdb_ctx_set_profiling(fvdb_ctx* ctx, int on);
+
+/* ---- IVF-flat ------------------------------------------------------------------------
+ * Replaces IVFIndex's arithmetic: find_nearest_centroid (src/ivf/core.rs:373-386), the
+ * coarse ranking + list scan + selection of search_with_config (:626-681) and
+ * batch_search (src/ivf/operations.rs:132-145).  Row ids are caller-chosen u64.
+ */
+int fvdb_ivf_create(fvdb_ctx* ctx, uint32_t d, uint32_t nlist, fvdb_ivf** out);
+void fvdb_ivf_destroy(fvdb_ivf* ivf);
+/* set_trained (src/ivf/core.rs:509-520): install nlist x d centroids (host), empty the lists. */
+int fvdb_ivf_set_centroids(fvdb_ivf* ivf, const float* centroids);
+int fvdb_ivf_get_centroids(fvdb_ivf* ivf, float* out /* nlist x d */);
+/* k-means++ + Lloyd on the GPU (src/ivf/core.rs:240-429).  Assignment = the coarse kernel;
+ * centroid update and error are summed in data order like the reference.  The seeding
+ * draws come from SplitMix64(seed) (the reference's StdRng stream is unpinned). */
+typedef struct fvdb_train_result {
+  uint32_t iterations;
+  uint32_t converged;
+  float initial_error;
+  float final_error;
+} fvdb_train_result;
+int fvdb_ivf_train(fvdb_ivf* ivf, const float* x, uint64_t n, uint32_t max_iterations, uint64_t seed,
+                   fvdb_train_result* out);
+/* Batched find_nearest_centroid: strict '<', lowest cluster id wins ties. */
+int fvdb_ivf_assign(fvdb_ivf* ivf, const float* x, uint64_t n, uint32_t* out_cluster);
+/* insert (src/ivf/core.rs:431-455) for n rows: assign on the GPU, append to the lists in row
+ * order.  out_cluster/out_pos (optional) receive each row's list and position in it. */
+int fvdb_ivf_add(fvdb_ivf* ivf, const float* x, const uint64_t* ids, uint64_t n, uint32_t* out_cluster,
+                 uint32_t* out_pos);
+/* Append rows whose cluster is already known (load path, shard placement). */
+int fvdb_ivf_add_assigned(fvdb_ivf* ivf, const float* x, const uint64_t* ids, uint64_t n,
+                          const uint32_t* cluster, uint32_t* out_pos);
+/* Soft delete (src/ivf/operations.rs:569-591 + the skip at src/ivf/core.rs:666-669). */
+int fvdb_ivf_set_deleted(fvdb_ivf* ivf, const uint32_t* cluster, const uint32_t* pos, uint64_t n, int deleted);
+int fvdb_ivf_list_sizes(fvdb_ivf* ivf, uint64_t* out /* nlist */);
+uint64_t fvdb_ivf_total_rows(fvdb_ivf* ivf);
+int fvdb_ivf_reserve(fvdb_ivf* ivf, uint64_t n_rows);
+int fvdb_ivf_clear(fvdb_ivf* ivf);   /* empties the lists, keeps centroids (hybrid initialize :278-287) */
+/* Multi-GPU: sizes of ALL lists of the logical index (this rank may own a subset), so the
+ * tie-break position `seq` is identical on every rank.  Default = local sizes. */
+int fvdb_ivf_set_global_list_sizes(fvdb_ivf* ivf, const uint64_t* sizes /* nlist */);
+
+/* search_with_config for B queries.  out_ids/out_dist are B x k (unused tail = FVDB_NO_ID /
+ * +inf), out_counts[B] the number of hits.  nprobe > nlist probes every list. */
+int fvdb_ivf_search(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t k, uint32_t nprobe, uint64_t* out_ids,
+                    float* out_dist, uint32_t* out_counts);
+/* Same with device pointers.  q is B x d row-major f32 in HBM.  out_keys (optional, B x k u64)
+ * receives (distance bits << 32 | seq): the total order used for selection; unique per row, so
+ * per-GPU partial results can be merged exactly (fvdb_merge_keys_dev). */
+int fvdb_ivf_search_dev(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t k, uint32_t nprobe,
+                        uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev,
+                        uint64_t* out_keys_dev);
+/* Exhaustive scan of every list (exact k-NN; ground truth for recall, and the a7/a8 kernel
+ * with no coarse step). */
+int fvdb_ivf_search_all(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t k, uint64_t* out_ids,
+                        float* out_dist, uint32_t* out_counts);
+int fvdb_ivf_search_all_dev(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t k, uint64_t* out_ids_dev,
+                            float* out_dist_dev, uint32_t* out_counts_dev);
+/* Coarse step alone (src/ivf/core.rs:645-656): the nprobe nearest clusters per query in
+ * probe order, and their distances. */
+int fvdb_ivf_coarse(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t nprobe, uint32_t* out_clusters,
+                    float* out_dist);
+
+/* Counters of the last search on this index (for roofline accounting). */
+typedef struct fvdb_search_stats {
+  uint64_t rows_scanned;      /* sum over queries of rows in probed lists (algorithmic) */
+  uint64_t work_items;        /* (list segment, query group) items executed */
+  uint64_t list_rows_touched; /* rows of the union of probed lists (physical lower bound) */
+} fvdb_search_stats;
+int fvdb_ivf_last_stats(fvdb_ivf* ivf, fvdb_search_stats* out);
+/* With profiling on: ms[5] = coarse scan, coarse merge, plan, fine scan, fine merge, summed over the
+ * searches since the last call; returns how many searches (sub-batches) were accumulated. */
+uint64_t fvdb_ivf_stage_times(fvdb_ivf* ivf, float* ms_out);
+
+/* ---- merge ---------------------------------------------------------------------------
+ * G-way merge of per-shard partial top-k by key (a4/a12 semantics: ascending, keep k).
+ * keys/ids: G x B x k (device).  Exact because keys are unique. */
+int fvdb_merge_keys_dev(fvdb_ctx* ctx, const uint64_t* keys_dev, const uint64_t* ids_dev, uint32_t G, uint32_t B,
+                        uint32_t k, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev);
+
+/* ---- candidate scoring (HNSW) --------------------------------------------------------
+ * Replaces euclidean_distance at src/hnsw/core.rs:279,434,487,515 (search_layer) and
+ * :573,605,611 (prune): the host walks the graph, each hop's candidate batch is scored here.
+ */
+int fvdb_store_create(fvdb_ctx* ctx, uint32_t d, uint64_t capacity_rows, fvdb_store** out);
+void fvdb_store_destroy(fvdb_store* s);
+int fvdb_store_append(fvdb_store* s, const float* rows, uint64_t n, uint64_t* first_row);
+uint64_t fvdb_store_rows(fvdb_store* s);
+int fvdb_store_get(fvdb_store* s, uint64_t row, float* out /* d */);
+/* One-shot: B queries (host), C candidate row indices per query (FVDB_NO_ROW = pad) -> B x C
+ * distances (+inf for pads). */
+int fvdb_score_candidates(fvdb_store* s, const float* q, uint32_t B, const uint32_t* cand, uint32_t C, float* out);
+/* Hop loop: queries stay in HBM, candidates/distances travel through pinned host memory
+ * mapped into the GPU (no memcpy calls): one launch + one stream sync per hop. */
+typedef struct fvdb_scorer fvdb_scorer;
+int fvdb_scorer_create(fvdb_store* s, uint32_t max_B, uint32_t max_C, fvdb_scorer** out);
+void fvdb_scorer_destroy(fvdb_scorer* sc);
+int fvdb_scorer_set_queries(fvdb_scorer* sc, const float* q, uint32_t B);      /* host rows */
+int fvdb_scorer_set_query_rows(fvdb_scorer* sc, const uint32_t* rows, uint32_t B); /* queries = stored rows */
+uint32_t* fvdb_scorer_cand_buffer(fvdb_scorer* sc);   /* B x max_C, write candidates here */
+const float* fvdb_scorer_dist_buffer(fvdb_scorer* sc); /* B x max_C, read distances here */
+int fvdb_scorer_run(fvdb_scorer* sc, uint32_t B, uint32_t C); /* scores cand_buffer[0..B x C) (stride C) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FVDB_H */
