@@ -11,3 +11,4 @@ The directory name carries a hyphen, so import it through `fvdb_import.py` at th
 from . import _capi  # noqa: F401
 from .engine import *  # noqa: F401,F403
 from .engine import Context, DeviceIVF, RowStore  # noqa: F401
+from .index import IVFIndex, HNSWIndex, HybridIndex, SearchResults, load_host  # noqa: F401,E402

@@ -1,0 +1,173 @@
+// capi.cpp — flat C view of the host mirror for ctypes (fvh_* symbols).
+#include <cstring>
+#include <new>
+
+#include "fvdb_host.hpp"
+
+using namespace fvdbh;
+
+extern "C" {
+
+// ---- IVFIndex ----
+void* fvh_ivf_new(fvdb_ctx* ctx, uint32_t n_clusters, uint32_t n_probe, uint32_t train_size, uint32_t max_iterations,
+                  uint64_t seed) {
+  IVFConfig c;
+  c.n_clusters = n_clusters;
+  c.n_probe = n_probe;
+  c.train_size = train_size;
+  c.max_iterations = max_iterations;
+  c.seed = seed;
+  if (!c.is_valid()) return nullptr;  // IVFIndex::new panics on an invalid config (:171-174)
+  return new (std::nothrow) IVFIndex(ctx, c);
+}
+void fvh_ivf_free(void* p) { delete (IVFIndex*)p; }
+int fvh_ivf_train(void* p, const float* x, uint64_t n, uint32_t d, fvdb_train_result* out) {
+  return ((IVFIndex*)p)->train(x, n, d, out);
+}
+int fvh_ivf_set_trained(void* p, const float* c, uint32_t d) { return ((IVFIndex*)p)->set_trained(c, d); }
+int fvh_ivf_get_centroids(void* p, float* out) { return ((IVFIndex*)p)->get_centroids(out); }
+int fvh_ivf_is_trained(void* p) { return ((IVFIndex*)p)->is_trained(); }
+uint32_t fvh_ivf_dimension(void* p) { return ((IVFIndex*)p)->dimension(); }
+uint64_t fvh_ivf_total_vectors(void* p) { return ((IVFIndex*)p)->total_vectors(); }
+uint64_t fvh_ivf_active_count(void* p) { return ((IVFIndex*)p)->active_count(); }
+uint64_t fvh_ivf_cluster_size(void* p, uint32_t c) { return ((IVFIndex*)p)->cluster_size(c); }
+int fvh_ivf_insert(void* p, uint64_t id, const float* v, uint32_t d) { return ((IVFIndex*)p)->insert(id, v, d); }
+int fvh_ivf_batch_insert(void* p, const uint64_t* ids, const float* v, uint64_t n, uint32_t d, uint64_t* n_ok,
+                         int* first_error) {
+  return ((IVFIndex*)p)->batch_insert(ids, v, n, d, n_ok, first_error);
+}
+int fvh_ivf_find_cluster(void* p, const float* v, uint32_t d, uint32_t* out) {
+  return ((IVFIndex*)p)->find_cluster(v, d, out);
+}
+int fvh_ivf_search(void* p, const float* q, uint32_t B, uint32_t d, uint32_t k, uint32_t n_probe, uint64_t* ids,
+                   float* dist, uint32_t* counts) {
+  return ((IVFIndex*)p)->search(q, B, d, k, n_probe, ids, dist, counts);
+}
+int fvh_ivf_mark_deleted(void* p, uint64_t id) { return ((IVFIndex*)p)->mark_deleted(id); }
+int fvh_ivf_is_deleted(void* p, uint64_t id) { return ((IVFIndex*)p)->is_deleted(id); }
+void* fvh_ivf_device(void* p) { return ((IVFIndex*)p)->device(); }
+
+// ---- HNSWIndex ----
+void* fvh_hnsw_new(fvdb_ctx* ctx, uint32_t M, uint32_t M0, uint32_t efc, uint64_t seed) {
+  HNSWConfig c;
+  c.max_connections = M;
+  c.max_connections_layer_0 = M0;
+  c.ef_construction = efc;
+  c.seed = seed;
+  return new (std::nothrow) HNSWIndex(ctx, c);
+}
+void fvh_hnsw_free(void* p) { delete (HNSWIndex*)p; }
+int fvh_hnsw_insert(void* p, uint64_t id, const float* v, uint32_t d, int64_t level) {
+  return ((HNSWIndex*)p)->insert(id, v, d, level);
+}
+// batch_insert (src/hnsw/operations.rs:74-94): sequential loop, keeps going after a failure
+int fvh_hnsw_batch_insert(void* p, const uint64_t* ids, const float* v, uint64_t n, uint32_t d, const int64_t* levels,
+                          uint64_t* n_ok, int* first_error) {
+  uint64_t ok = 0;
+  int err = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    int rc = ((HNSWIndex*)p)->insert(ids[i], v + i * d, d, levels ? levels[i] : -1);
+    if (rc == 0) ++ok; else if (!err) err = rc;
+  }
+  if (n_ok) *n_ok = ok;
+  if (first_error) *first_error = err;
+  return 0;
+}
+int fvh_hnsw_search(void* p, const float* q, uint32_t B, uint32_t d, uint32_t k, uint32_t ef, uint64_t* ids,
+                    float* dist, uint32_t* counts) {
+  return ((HNSWIndex*)p)->search(q, B, d, k, ef, ids, dist, counts);
+}
+uint64_t fvh_hnsw_node_count(void* p) { return ((HNSWIndex*)p)->node_count(); }
+uint64_t fvh_hnsw_active_count(void* p) { return ((HNSWIndex*)p)->active_count(); }
+int fvh_hnsw_entry_point(void* p, uint64_t* out) { return ((HNSWIndex*)p)->entry_point(out) ? 0 : FVDB_E_NOT_FOUND; }
+int64_t fvh_hnsw_level(void* p, uint64_t id) { return ((HNSWIndex*)p)->level_of(id); }
+int64_t fvh_hnsw_neighbors(void* p, uint64_t id, uint32_t layer, uint64_t* out, uint64_t cap) {
+  return ((HNSWIndex*)p)->neighbors(id, layer, out, cap);
+}
+int fvh_hnsw_mark_deleted(void* p, uint64_t id) { return ((HNSWIndex*)p)->mark_deleted(id); }
+int fvh_hnsw_is_deleted(void* p, uint64_t id) { return ((HNSWIndex*)p)->is_deleted(id); }
+int fvh_hnsw_bulk_build(void* p, const uint64_t* ids, const float* v, uint64_t n, uint32_t d, const int64_t* levels) {
+  return ((HNSWIndex*)p)->bulk_build(ids, v, n, d, levels);
+}
+int fvh_hnsw_restore(void* p, const uint64_t* ids, const float* v, uint64_t n, uint32_t d, const uint32_t* levels,
+                     const uint64_t* off, const uint64_t* nbrs, uint64_t entry) {
+  return ((HNSWIndex*)p)->restore(ids, v, n, d, levels, off, nbrs, entry);
+}
+uint64_t fvh_hnsw_graph_slots(void* p) { return ((HNSWIndex*)p)->graph_slots(); }
+uint64_t fvh_hnsw_graph_edges(void* p) { return ((HNSWIndex*)p)->graph_edges(); }
+void fvh_hnsw_export_graph(void* p, uint64_t* ids, uint32_t* levels, uint64_t* off, uint64_t* nbrs) {
+  ((HNSWIndex*)p)->export_graph(ids, levels, off, nbrs);
+}
+int fvh_hnsw_get_vector(void* p, uint64_t id, float* out) {
+  HNSWIndex* h = (HNSWIndex*)p;
+  const float* v = h->vector_of(id);
+  if (!v) return FVDB_E_NOT_FOUND;
+  std::memcpy(out, v, h->dimension() * sizeof(float));
+  return 0;
+}
+uint64_t fvh_hnsw_dist_evals(void* p) { return ((HNSWIndex*)p)->dist_evals(); }
+uint64_t fvh_hnsw_hops(void* p) { return ((HNSWIndex*)p)->hops(); }
+void fvh_hnsw_set_threads(void* p, int t) { ((HNSWIndex*)p)->set_threads(t); }
+uint32_t fvh_hnsw_dimension(void* p) { return ((HNSWIndex*)p)->dimension(); }
+
+// ---- HybridIndex ----
+void* fvh_hybrid_new(fvdb_ctx* ctx_ivf, fvdb_ctx* ctx_hnsw, double recent_threshold_s, uint64_t migration_batch_size,
+                     int auto_migrate, uint64_t min_ivf_training_size, uint32_t M, uint32_t M0, uint32_t efc,
+                     uint64_t hseed, uint32_t n_clusters, uint32_t n_probe, uint32_t train_size, uint32_t max_iter,
+                     uint64_t iseed) {
+  HybridConfig c;
+  c.recent_threshold_s = recent_threshold_s;
+  c.migration_batch_size = migration_batch_size;
+  c.auto_migrate = auto_migrate != 0;
+  c.min_ivf_training_size = min_ivf_training_size;
+  c.hnsw.max_connections = M;
+  c.hnsw.max_connections_layer_0 = M0;
+  c.hnsw.ef_construction = efc;
+  c.hnsw.seed = hseed;
+  c.ivf.n_clusters = n_clusters;
+  c.ivf.n_probe = n_probe;
+  c.ivf.train_size = train_size;
+  c.ivf.max_iterations = max_iter;
+  c.ivf.seed = iseed;
+  if (!c.ivf.is_valid() || !(recent_threshold_s > 0) || migration_batch_size == 0) return nullptr;
+  return new (std::nothrow) HybridIndex(ctx_ivf, ctx_hnsw, c);
+}
+void fvh_hybrid_free(void* p) { delete (HybridIndex*)p; }
+int fvh_hybrid_initialize(void* p, const float* x, uint64_t n, uint32_t d) {
+  return ((HybridIndex*)p)->initialize(x, n, d);
+}
+int fvh_hybrid_set_ivf_centroids(void* p, const float* c, uint32_t d) {
+  return ((HybridIndex*)p)->set_ivf_centroids(c, d);
+}
+int fvh_hybrid_insert(void* p, uint64_t id, const float* v, uint32_t d, double ts, double now, int64_t level) {
+  return ((HybridIndex*)p)->insert_with_timestamp(id, v, d, ts, now, level);
+}
+int fvh_hybrid_bulk_insert(void* p, const uint64_t* ids, const float* v, uint64_t n, uint32_t d, const double* ts,
+                           double now) {
+  return ((HybridIndex*)p)->bulk_insert(ids, v, n, d, ts, now);
+}
+int fvh_hybrid_search(void* p, const float* q, uint32_t B, uint32_t d, uint64_t k, uint64_t ef, uint64_t nprobe,
+                      int search_recent, int search_historical, uint64_t recent_k, uint64_t historical_k, double now,
+                      uint64_t* ids, float* dist, uint32_t* counts) {
+  HybridSearchConfig c;
+  c.k = k;
+  c.hnsw_ef = ef;
+  c.ivf_n_probe = nprobe;
+  c.search_recent = search_recent != 0;
+  c.search_historical = search_historical != 0;
+  c.recent_k = recent_k;
+  c.historical_k = historical_k;
+  return ((HybridIndex*)p)->search(q, B, d, c, now, ids, dist, counts);
+}
+int fvh_hybrid_delete(void* p, uint64_t id, double now) { return ((HybridIndex*)p)->remove(id, now); }
+uint64_t fvh_hybrid_migrate(void* p, double thr, double now) {
+  return ((HybridIndex*)p)->migrate_with_threshold(thr, now);
+}
+uint64_t fvh_hybrid_recent_count(void* p) { return ((HybridIndex*)p)->recent_count(); }
+uint64_t fvh_hybrid_historical_count(void* p) { return ((HybridIndex*)p)->historical_count(); }
+int fvh_hybrid_is_initialized(void* p) { return ((HybridIndex*)p)->is_initialized(); }
+int fvh_hybrid_is_ivf_trained(void* p) { return ((HybridIndex*)p)->is_ivf_trained(); }
+void* fvh_hybrid_hnsw(void* p) { return &((HybridIndex*)p)->recent(); }
+void* fvh_hybrid_ivf(void* p) { return &((HybridIndex*)p)->historical(); }
+
+}  // extern "C"

@@ -1,0 +1,248 @@
+// fvdb_host.hpp — host-side mirror of the reference's index classes for the hot path.
+//
+// The reference's host code is Rust (src/ivf/core.rs, src/hnsw/core.rs, src/hybrid/core.rs);
+// no Rust toolchain exists here, so the mirror is C++ above the C ABI (include/fvdb.h), with
+// the same names, argument meaning and error behaviour.  It owns the index STRUCTURES (lists
+// bookkeeping, HNSW graph, heaps, visited sets, routing, timestamps); every distance comes
+// from the GPU through the C ABI.  Nothing in here computes a vector distance on the CPU.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/fvdb.h"
+
+namespace fvdbh {
+
+// Documented PRNG for this build's own draws (HNSW levels, k-means++): SplitMix64.
+// The reference uses rand 0.8 StdRng whose stream cannot be reproduced here.
+struct SplitMix64 {
+  uint64_t s;
+  explicit SplitMix64(uint64_t seed) : s(seed) {}
+  uint64_t next() {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  double gen_f64() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+struct Cand {
+  uint32_t node;   // node index (HNSW) — ids are resolved at the API boundary
+  float distance;
+};
+
+// std::collections::BinaryHeap restated (sift_up / sift_down_to_bottom), so exact distance
+// ties resolve like the reference's heaps.  Ordering: SearchCandidate::cmp, src/hnsw/core.rs:126-137.
+struct RustHeap {
+  std::vector<Cand> data;
+  static bool le(const Cand& a, const Cand& b) { return a.distance >= b.distance; }
+  size_t len() const { return data.size(); }
+  bool empty() const { return data.empty(); }
+  const Cand& peek() const { return data[0]; }
+  void clear() { data.clear(); }
+  void sift_up(size_t start, size_t pos);
+  void push(Cand c);
+  Cand pop();
+};
+
+// Open-addressing visited set with O(1) reset.
+struct Visited {
+  std::vector<uint32_t> keys, stamp;
+  uint32_t epoch = 0, used = 0;
+  void reset(size_t expect);
+  bool insert(uint32_t v);  // true if newly inserted
+ private:
+  void grow();
+};
+
+// ------------------------------------------------------------------------------------------
+// IVFIndex — src/ivf/core.rs, src/ivf/operations.rs
+// ------------------------------------------------------------------------------------------
+struct IVFConfig {
+  uint32_t n_clusters = 256, n_probe = 16, train_size = 10000, max_iterations = 25;  // :50-60
+  uint64_t seed = 0;
+  bool is_valid() const { return n_clusters > 0 && n_probe > 0 && n_probe <= n_clusters && train_size > 0 && max_iterations > 0; }
+};
+
+class IVFIndex {
+ public:
+  IVFIndex(fvdb_ctx* ctx, const IVFConfig& cfg);
+  ~IVFIndex();
+  const IVFConfig& config() const { return cfg_; }
+  bool is_trained() const { return trained_; }
+  uint32_t dimension() const { return dim_; }
+  uint64_t total_vectors() const { return total_; }
+  int train(const float* data, uint64_t n, uint32_t dim, fvdb_train_result* out);  // :240
+  int set_trained(const float* centroids, uint32_t dim);                          // :509
+  int get_centroids(float* out) const;
+  int insert(uint64_t id, const float* v, uint32_t dim);                          // :431
+  // batch_insert (operations.rs:107-130): sequential semantics, one GPU assignment pass.
+  int batch_insert(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, uint64_t* n_ok, int* first_error);
+  int find_cluster(const float* v, uint32_t dim, uint32_t* out);                  // :493
+  int search(const float* q, uint32_t B, uint32_t dim, uint32_t k, uint32_t n_probe, uint64_t* ids, float* dist,
+             uint32_t* counts);                                                   // :626, operations.rs:132
+  int mark_deleted(uint64_t id);                                                  // operations.rs:569
+  bool is_deleted(uint64_t id) const { return deleted_.count(id) > 0; }
+  uint64_t active_count() const { return total_ - deleted_.size(); }
+  uint64_t cluster_size(uint32_t c) const;
+  void clear_lists();                                                             // hybrid initialize :278-287
+  fvdb_ivf* device() { return dev_; }
+
+ private:
+  struct Loc {
+    uint32_t cluster, pos;
+  };
+  int ensure_device(uint32_t dim);
+  int place(const uint64_t* ids, const float* v, uint64_t n, const uint32_t* clusters, uint64_t* n_ok, int* first_error);
+  fvdb_ctx* ctx_;
+  IVFConfig cfg_;
+  fvdb_ivf* dev_ = nullptr;
+  uint32_t dim_ = 0;
+  bool trained_ = false;
+  uint64_t total_ = 0;
+  std::unordered_multimap<uint64_t, Loc> where_;  // id -> every list position holding it
+  std::unordered_set<uint64_t> deleted_;
+};
+
+// ------------------------------------------------------------------------------------------
+// HNSWIndex — src/hnsw/core.rs, src/hnsw/operations.rs
+// ------------------------------------------------------------------------------------------
+struct HNSWConfig {
+  uint32_t max_connections = 16, max_connections_layer_0 = 32, ef_construction = 200;  // :37-46
+  uint64_t seed = 0;
+};
+
+class HNSWIndex {
+ public:
+  HNSWIndex(fvdb_ctx* ctx, const HNSWConfig& cfg);
+  ~HNSWIndex();
+  const HNSWConfig& config() const { return cfg_; }
+  uint64_t node_count() const { return n_registered_; }
+  bool entry_point(uint64_t* id) const;
+  uint32_t dimension() const { return dim_; }
+  size_t assign_level();                                                           // :211
+  int insert(uint64_t id, const float* v, uint32_t dim, int64_t forced_level);     // :226
+  int search(const float* q, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
+             uint32_t* counts);                                                    // :398 (batched, lock-step hops)
+  int mark_deleted(uint64_t id);                                                   // operations.rs:127
+  bool is_deleted(uint64_t id) const;
+  uint64_t active_count() const;
+  int64_t level_of(uint64_t id) const;
+  int64_t neighbors(uint64_t id, uint32_t layer, uint64_t* out, uint64_t cap) const;
+  const float* vector_of(uint64_t id) const;  // host copy (migration, get_vector_by_id)
+  bool contains(uint64_t id) const { return index_of_.count(id) > 0; }
+  // Extension (not in the reference): build the graph for n vectors at once.  Levels from the PRNG
+  // (or given); per layer every member links to its exact nearest M (M0 on layer 0) members, found
+  // with the GPU flat scan — the graph nearest-M selection (:556-558, :588-624) converges to.
+  int bulk_build(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const int64_t* levels);
+  // Install / export a graph (identical structures for parity runs).
+  int restore(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const uint32_t* levels,
+              const uint64_t* nbr_offsets, const uint64_t* nbrs, uint64_t entry_id);
+  uint64_t graph_slots() const;
+  uint64_t graph_edges() const;
+  void export_graph(uint64_t* ids, uint32_t* levels, uint64_t* nbr_offsets, uint64_t* nbrs) const;
+  uint64_t dist_evals() const { return n_dist_; }
+  uint64_t hops() const { return n_hops_; }
+  void set_threads(int t) { threads_ = t; }
+
+ private:
+  struct Query {
+    RustHeap candidates, nearest;
+    Visited visited;
+    std::vector<uint32_t> pending;  // candidates sent to the GPU this hop
+    bool active = false;
+  };
+  uint32_t cap(uint32_t layer) const { return layer == 0 ? cfg_.max_connections_layer_0 : cfg_.max_connections; }
+  std::vector<uint32_t>& nb(uint32_t node, uint32_t layer) { return nbrs_[node][layer]; }
+  int ensure_store(uint32_t dim);
+  int ensure_scorer(uint32_t B, uint32_t C);
+  int append_row(const float* v, uint32_t* row);
+  // lock-step search_layer (:469-554) for B queries already loaded into the scorer
+  int search_layer_batch(uint32_t B, const std::vector<Cand>& entries, const std::vector<uint8_t>& has_entry,
+                         uint32_t ef, uint32_t layer, std::vector<std::vector<Cand>>& results);
+  int score_pairs_from_row(uint32_t base_row, const std::vector<uint32_t>& cands, std::vector<float>& out);
+
+  fvdb_ctx* ctx_;
+  HNSWConfig cfg_;
+  SplitMix64 rng_;
+  fvdb_store* store_ = nullptr;
+  fvdb_scorer* scorer_ = nullptr;
+  uint32_t scorer_B_ = 0, scorer_C_ = 0;
+  uint32_t dim_ = 0;
+  bool has_dim_ = false, has_entry_ = false;
+  uint32_t entry_ = 0;
+  uint64_t n_registered_ = 0;
+  std::vector<uint64_t> ids_;
+  std::vector<uint32_t> level_;
+  std::vector<uint8_t> deleted_, registered_;
+  std::vector<std::vector<std::vector<uint32_t>>> nbrs_;  // [node][layer] insertion-ordered sets
+  std::unordered_map<uint64_t, uint32_t> index_of_;
+  std::vector<float> host_vecs_;
+  std::vector<Query> qs_;
+  uint64_t n_dist_ = 0, n_hops_ = 0;
+  int threads_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// HybridIndex — src/hybrid/core.rs.  `now` / timestamps are seconds passed in by the caller
+// (the reference reads Utc::now() at the same points).
+// ------------------------------------------------------------------------------------------
+struct HybridConfig {
+  double recent_threshold_s = 7.0 * 24 * 3600;  // :77
+  HNSWConfig hnsw;
+  IVFConfig ivf;  // default() below sets 3 clusters / n_probe 2 / train_size 9 like :69-74
+  uint64_t migration_batch_size = 100;
+  bool auto_migrate = true;
+  uint64_t min_ivf_training_size = 10;
+  static HybridConfig defaults() {
+    HybridConfig c;
+    c.ivf.train_size = 9;
+    c.ivf.n_clusters = 3;
+    c.ivf.n_probe = 2;
+    return c;
+  }
+};
+
+struct HybridSearchConfig {  // :172-197
+  bool search_recent = true, search_historical = true;
+  uint64_t recent_k = 0, historical_k = 0;
+  uint64_t k = 10, hnsw_ef = 50, ivf_n_probe = 10;
+};
+
+class HybridIndex {
+ public:
+  HybridIndex(fvdb_ctx* ctx_ivf, fvdb_ctx* ctx_hnsw, const HybridConfig& cfg);
+  ~HybridIndex();
+  bool is_initialized() const { return initialized_; }
+  bool is_ivf_trained() const { return ivf_trained_; }
+  int initialize(const float* data, uint64_t n, uint32_t dim);                                    // :262
+  int set_ivf_centroids(const float* c, uint32_t dim);  // install a trained quantizer (parity runs)
+  int insert_with_timestamp(uint64_t id, const float* v, uint32_t dim, double ts, double now, int64_t level);  // :357
+  int search(const float* q, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg, double now, uint64_t* ids,
+             float* dist, uint32_t* counts);                                                       // :425
+  uint64_t migrate_with_threshold(double threshold_s, double now);                                // :600
+  int remove(uint64_t id, double now);                                                             // delete :904
+  uint64_t recent_count() const { return recent_count_; }
+  uint64_t historical_count() const { return historical_count_; }
+  HNSWIndex& recent() { return *recent_; }
+  IVFIndex& historical() { return *historical_; }
+  // bulk loaders for scale runs: route by age like insert_with_timestamp, batched on the GPU
+  int bulk_insert(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const double* ts, double now);
+
+ private:
+  static double age_of(double now, double ts) { return now - ts < 0 ? 0.0 : now - ts; }
+  HybridConfig cfg_;
+  HNSWIndex* recent_;
+  IVFIndex* historical_;
+  bool initialized_ = false, ivf_trained_ = false;
+  std::vector<uint64_t> ts_order_;
+  std::unordered_map<uint64_t, double> timestamps_;
+  std::vector<uint64_t> pending_migration_;  // ids living in HNSW whose copy into IVF has not succeeded
+  uint64_t recent_count_ = 0, historical_count_ = 0;
+};
+
+}  // namespace fvdbh

@@ -1,0 +1,606 @@
+// hnsw_index.cpp — HNSWIndex mirror (src/hnsw/core.rs, src/hnsw/operations.rs).
+// The graph, heaps and visited sets live here; every distance is scored on the GPU through
+// fvdb_scorer_* (one launch per hop for the whole query batch, candidates and distances
+// travelling through pinned host memory mapped into the GPU).
+#include <omp.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "fvdb_host.hpp"
+
+namespace fvdbh {
+
+// ---- RustHeap ------------------------------------------------------------------------------
+void RustHeap::sift_up(size_t start, size_t pos) {
+  Cand elt = data[pos];
+  while (pos > start) {
+    size_t parent = (pos - 1) / 2;
+    if (le(elt, data[parent])) break;
+    data[pos] = data[parent];
+    pos = parent;
+  }
+  data[pos] = elt;
+}
+void RustHeap::push(Cand c) {
+  size_t old = data.size();
+  data.push_back(c);
+  sift_up(0, old);
+}
+Cand RustHeap::pop() {
+  Cand item = data.back();
+  data.pop_back();
+  if (!data.empty()) {
+    std::swap(item, data[0]);
+    const size_t end = data.size();
+    size_t pos = 0;
+    Cand elt = data[0];
+    size_t child = 1;
+    const size_t lim = end >= 2 ? end - 2 : 0;
+    while (child <= lim) {
+      if (le(data[child], data[child + 1])) child += 1;
+      data[pos] = data[child];
+      pos = child;
+      child = 2 * pos + 1;
+    }
+    if (child == end - 1) {
+      data[pos] = data[child];
+      pos = child;
+    }
+    data[pos] = elt;
+    sift_up(0, pos);
+  }
+  return item;
+}
+
+// ---- Visited -------------------------------------------------------------------------------
+void Visited::reset(size_t expect) {
+  size_t want = 64;
+  while (want < expect * 2) want <<= 1;
+  if (keys.size() < want) {
+    keys.assign(want, 0);
+    stamp.assign(want, 0);
+    epoch = 0;
+  }
+  epoch += 1;
+  if (epoch == 0) {  // wrapped
+    std::fill(stamp.begin(), stamp.end(), 0u);
+    epoch = 1;
+  }
+  used = 0;
+}
+void Visited::grow() {
+  std::vector<uint32_t> ok;
+  ok.reserve(used);
+  for (size_t i = 0; i < keys.size(); ++i)
+    if (stamp[i] == epoch) ok.push_back(keys[i]);
+  const size_t nsz = keys.size() * 2;
+  keys.assign(nsz, 0);
+  stamp.assign(nsz, 0);
+  epoch = 1;
+  used = 0;
+  for (uint32_t v : ok) insert(v);
+}
+bool Visited::insert(uint32_t v) {
+  if ((used + 1) * 2 > keys.size()) grow();
+  const size_t mask = keys.size() - 1;
+  size_t h = (v * 2654435761u) & mask;
+  for (;;) {
+    if (stamp[h] != epoch) {
+      stamp[h] = epoch;
+      keys[h] = v;
+      used++;
+      return true;
+    }
+    if (keys[h] == v) return false;
+    h = (h + 1) & mask;
+  }
+}
+
+static inline bool set_insert(std::vector<uint32_t>& s, uint32_t v) {
+  if (std::find(s.begin(), s.end(), v) != s.end()) return false;
+  s.push_back(v);
+  return true;
+}
+
+// ---- HNSWIndex -----------------------------------------------------------------------------
+HNSWIndex::HNSWIndex(fvdb_ctx* ctx, const HNSWConfig& cfg) : ctx_(ctx), cfg_(cfg), rng_(cfg.seed) {}
+
+HNSWIndex::~HNSWIndex() {
+  if (scorer_) fvdb_scorer_destroy(scorer_);
+  if (store_) fvdb_store_destroy(store_);
+}
+
+bool HNSWIndex::entry_point(uint64_t* id) const {
+  if (!has_entry_) return false;
+  *id = ids_[entry_];
+  return true;
+}
+
+// src/hnsw/core.rs:211-224
+size_t HNSWIndex::assign_level() {
+  size_t level = 0;
+  while (rng_.gen_f64() < 0.408) level += 1;
+  return level;
+}
+
+int HNSWIndex::ensure_store(uint32_t dim) {
+  if (store_) return FVDB_OK;
+  return fvdb_store_create(ctx_, dim, 1024, &store_);
+}
+
+int HNSWIndex::ensure_scorer(uint32_t B, uint32_t C) {
+  if (scorer_ && scorer_B_ >= B && scorer_C_ >= C) return FVDB_OK;
+  if (scorer_) fvdb_scorer_destroy(scorer_);
+  scorer_ = nullptr;
+  scorer_B_ = std::max(B, scorer_B_);
+  scorer_C_ = std::max(C, scorer_C_);
+  return fvdb_scorer_create(store_, scorer_B_, scorer_C_, &scorer_);
+}
+
+int HNSWIndex::append_row(const float* v, uint32_t* row) {
+  uint64_t first = 0;
+  int rc = fvdb_store_append(store_, v, 1, &first);
+  if (rc) return rc;
+  *row = (uint32_t)first;
+  host_vecs_.insert(host_vecs_.end(), v, v + dim_);
+  return FVDB_OK;
+}
+
+const float* HNSWIndex::vector_of(uint64_t id) const {
+  auto it = index_of_.find(id);
+  return it == index_of_.end() ? nullptr : &host_vecs_[(size_t)it->second * dim_];
+}
+
+int64_t HNSWIndex::level_of(uint64_t id) const {
+  auto it = index_of_.find(id);
+  return it == index_of_.end() ? -1 : (int64_t)level_[it->second];
+}
+
+int64_t HNSWIndex::neighbors(uint64_t id, uint32_t layer, uint64_t* out, uint64_t cap_out) const {
+  auto it = index_of_.find(id);
+  if (it == index_of_.end() || layer > level_[it->second]) return -1;
+  const auto& s = nbrs_[it->second][layer];
+  for (size_t i = 0; i < s.size() && i < cap_out; ++i) out[i] = ids_[s[i]];
+  return (int64_t)s.size();
+}
+
+// src/hnsw/operations.rs:127-137
+int HNSWIndex::mark_deleted(uint64_t id) {
+  auto it = index_of_.find(id);
+  if (it == index_of_.end()) return FVDB_E_NOT_FOUND;
+  deleted_[it->second] = 1;
+  return FVDB_OK;
+}
+bool HNSWIndex::is_deleted(uint64_t id) const {
+  auto it = index_of_.find(id);
+  return it != index_of_.end() && deleted_[it->second];
+}
+uint64_t HNSWIndex::active_count() const {
+  uint64_t n = 0;
+  for (size_t i = 0; i < ids_.size(); ++i)
+    if (registered_[i] && !deleted_[i]) ++n;
+  return n;
+}
+
+// --------------------------------------------------------------------------------------------
+// search_layer (src/hnsw/core.rs:469-554) for B queries in lock-step.  The queries are already
+// in the scorer.  Per hop every active query pops candidates until one of them has unvisited,
+// live neighbours; those go to the GPU in one launch; the admission rule (:517-531) is then
+// applied in neighbour order with the returned distances.
+// --------------------------------------------------------------------------------------------
+int HNSWIndex::search_layer_batch(uint32_t B, const std::vector<Cand>& entries, const std::vector<uint8_t>& has_entry,
+                                  uint32_t ef, uint32_t layer, std::vector<std::vector<Cand>>& results) {
+  if (qs_.size() < B) qs_.resize(B);
+  results.resize(B);
+  const uint32_t maxC = scorer_C_;
+  uint32_t* cand = fvdb_scorer_cand_buffer(scorer_);
+  const float* dist = fvdb_scorer_dist_buffer(scorer_);
+  const int nt = threads_ > 0 ? threads_ : omp_get_max_threads();
+  const bool par = B >= 32 && nt > 1;
+  std::vector<uint32_t> prev_cnt(B, maxC);  // rows start dirty: clear them on first use
+
+#pragma omp parallel for schedule(static) num_threads(nt) if (par)
+  for (uint32_t b = 0; b < B; ++b) {
+    Query& s = qs_[b];
+    s.candidates.clear();
+    s.nearest.clear();
+    s.pending.clear();
+    s.active = false;
+    results[b].clear();
+    if (!has_entry[b]) continue;
+    s.visited.reset((size_t)ef * 8 + 64);
+    const Cand e = entries[b];
+    s.candidates.push({e.node, e.distance});
+    s.nearest.push({e.node, -e.distance});
+    s.visited.insert(e.node);
+    s.active = true;
+  }
+
+  for (;;) {
+    uint32_t hopC = 0;
+    uint64_t hop_dists = 0;
+#pragma omp parallel for schedule(static) num_threads(nt) reduction(max : hopC) reduction(+ : hop_dists) if (par)
+    for (uint32_t b = 0; b < B; ++b) {
+      Query& s = qs_[b];
+      s.pending.clear();
+      if (s.active) {
+        for (;;) {
+          if (s.candidates.empty()) {
+            s.active = false;
+            break;
+          }
+          const Cand cur = s.candidates.pop();
+          if (cur.distance > -s.nearest.peek().distance) {  // :499-501
+            s.active = false;
+            break;
+          }
+          const uint32_t node = cur.node;
+          if (registered_[node] && level_[node] >= layer) {
+            for (uint32_t nbv : nbrs_[node][layer]) {
+              if (!s.visited.insert(nbv)) continue;  // :506-507
+              if (!registered_[nbv]) continue;       // nodes.get() == None (:509)
+              if (deleted_[nbv]) continue;           // :511-513
+              s.pending.push_back(nbv);
+            }
+          }
+          if (!s.pending.empty()) break;
+        }
+      }
+      uint32_t* row = cand + (size_t)b * maxC;
+      const uint32_t n = (uint32_t)s.pending.size();
+      for (uint32_t i = 0; i < n; ++i) row[i] = s.pending[i];
+      for (uint32_t i = n; i < prev_cnt[b]; ++i) row[i] = FVDB_NO_ROW;
+      prev_cnt[b] = n;
+      hopC = std::max(hopC, n);
+      hop_dists += n;
+    }
+    if (hopC == 0) break;
+    int rc = fvdb_scorer_run(scorer_, B, hopC);
+    if (rc) return rc;
+    n_hops_ += 1;
+    n_dist_ += hop_dists;
+#pragma omp parallel for schedule(static) num_threads(nt) if (par)
+    for (uint32_t b = 0; b < B; ++b) {
+      Query& s = qs_[b];
+      const float* drow = dist + (size_t)b * maxC;
+      for (size_t i = 0; i < s.pending.size(); ++i) {
+        const float d = drow[i];
+        if (d < -s.nearest.peek().distance || s.nearest.len() < ef) {  // :517-519
+          s.candidates.push({s.pending[i], d});
+          s.nearest.push({s.pending[i], -d});
+          if (s.nearest.len() > ef) s.nearest.pop();
+        }
+      }
+    }
+  }
+
+#pragma omp parallel for schedule(static) num_threads(nt) if (par)
+  for (uint32_t b = 0; b < B; ++b) {
+    if (!has_entry[b]) continue;
+    Query& s = qs_[b];
+    auto& r = results[b];
+    r.reserve(s.nearest.len());
+    for (const Cand& c : s.nearest.data) r.push_back({c.node, -c.distance});  // :541-547 (heap order)
+    std::stable_sort(r.begin(), r.end(), [](const Cand& a, const Cand& c) { return a.distance < c.distance; });
+  }
+  return FVDB_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// search (src/hnsw/core.rs:398-467), batched
+// --------------------------------------------------------------------------------------------
+int HNSWIndex::search(const float* q, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
+                      uint32_t* counts) {
+  for (uint32_t b = 0; b < B; ++b) counts[b] = 0;
+  for (size_t i = 0; i < (size_t)B * k; ++i) {
+    ids[i] = FVDB_NO_ID;
+    dist[i] = __builtin_huge_valf();
+  }
+  if (!has_entry_) return FVDB_OK;  // empty index -> empty results (:404-407)
+  if (has_dim_ && dim != dim_) return FVDB_E_DIM;
+  if (B == 0) return FVDB_OK;
+  const uint32_t step = 4096;
+  const uint32_t maxdeg = std::max(cfg_.max_connections, cfg_.max_connections_layer_0) + 1;
+  for (uint32_t o = 0; o < B; o += step) {
+    const uint32_t b = std::min(step, B - o);
+    int rc = ensure_scorer(b, maxdeg);
+    if (rc) return rc;
+    rc = fvdb_scorer_set_queries(scorer_, q + (size_t)o * dim, b);
+    if (rc) return rc;
+    // nearest = [(entry, dist(q, entry))]  (:432-435): one hop with a single candidate
+    uint32_t* cand = fvdb_scorer_cand_buffer(scorer_);
+    for (uint32_t i = 0; i < b; ++i) cand[(size_t)i * scorer_C_] = entry_;
+    rc = fvdb_scorer_run(scorer_, b, 1);
+    if (rc) return rc;
+    n_dist_ += b;
+    n_hops_ += 1;
+    const float* dbuf = fvdb_scorer_dist_buffer(scorer_);
+    std::vector<Cand> nearest0(b);
+    for (uint32_t i = 0; i < b; ++i) nearest0[i] = {entry_, dbuf[(size_t)i * scorer_C_]};
+    std::vector<uint8_t> has(b, 1);
+    std::vector<std::vector<Cand>> res, cur(b);
+    for (uint32_t i = 0; i < b; ++i) cur[i] = {nearest0[i]};
+    const uint32_t top = level_[entry_];
+    for (uint32_t lc = top + 1; lc-- > 0;) {
+      std::vector<Cand> entries(b);
+      for (uint32_t i = 0; i < b; ++i) entries[i] = cur[i][0];
+      rc = search_layer_batch(b, entries, has, lc == 0 ? ef : 1, lc, res);
+      if (rc) return rc;
+      for (uint32_t i = 0; i < b; ++i)
+        if (!res[i].empty()) cur[i].swap(res[i]);
+    }
+    for (uint32_t i = 0; i < b; ++i) {  // :451-466 filter deleted, take k
+      uint32_t w = 0;
+      for (const Cand& c : cur[i]) {
+        if (!registered_[c.node] || deleted_[c.node]) continue;
+        if (w >= k) break;
+        ids[(size_t)(o + i) * k + w] = ids_[c.node];
+        dist[(size_t)(o + i) * k + w] = c.distance;
+        ++w;
+      }
+      counts[o + i] = w;
+    }
+  }
+  return FVDB_OK;
+}
+
+// distances from stored row `base_row` to a list of candidate rows (prune: :588-624)
+int HNSWIndex::score_pairs_from_row(uint32_t base_row, const std::vector<uint32_t>& cands, std::vector<float>& out) {
+  int rc = fvdb_scorer_set_query_rows(scorer_, &base_row, 1);
+  if (rc) return rc;
+  uint32_t* cand = fvdb_scorer_cand_buffer(scorer_);
+  for (size_t i = 0; i < cands.size(); ++i) cand[i] = cands[i];
+  rc = fvdb_scorer_run(scorer_, 1, (uint32_t)cands.size());
+  if (rc) return rc;
+  n_dist_ += cands.size();
+  n_hops_ += 1;
+  const float* d = fvdb_scorer_dist_buffer(scorer_);
+  out.assign(d, d + cands.size());
+  for (size_t i = 0; i < cands.size(); ++i) cand[i] = FVDB_NO_ROW;
+  return FVDB_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// insert (src/hnsw/core.rs:226-378)
+// --------------------------------------------------------------------------------------------
+int HNSWIndex::insert(uint64_t id, const float* v, uint32_t dim, int64_t forced_level) {
+  if (index_of_.count(id)) return FVDB_E_DUPLICATE;
+  if (has_dim_ && dim != dim_) return FVDB_E_DIM;
+  if (!has_dim_) {
+    dim_ = dim;
+    has_dim_ = true;
+  }
+  int rc = ensure_store(dim);
+  if (rc) return rc;
+  const uint32_t level = forced_level >= 0 ? (uint32_t)forced_level : (uint32_t)assign_level();
+  uint32_t row = 0;
+  rc = append_row(v, &row);  // the vector is resident before the graph links to it
+  if (rc) return rc;
+  ids_.push_back(id);
+  level_.push_back(level);
+  deleted_.push_back(0);
+  registered_.push_back(0);  // "not yet in the nodes map" while its links are being made (:370)
+  nbrs_.emplace_back(level + 1);
+
+  bool is_first = false;
+  if (!has_entry_) {
+    has_entry_ = true;
+    entry_ = row;
+    is_first = true;
+  }
+  uint32_t entry_level = 0;
+  if (!is_first) {
+    const uint32_t ep = entry_;
+    entry_level = level_[ep];
+    const uint32_t maxdeg = std::max(cfg_.max_connections, cfg_.max_connections_layer_0) + 1;
+    rc = ensure_scorer(1, maxdeg);
+    if (rc) return rc;
+    std::vector<float> d0;
+    rc = score_pairs_from_row(row, {ep}, d0);  // also loads the new vector as the scorer's query
+    if (rc) return rc;
+    std::vector<Cand> current_nearest{{ep, d0[0]}};
+    const uint32_t search_level = std::min(level, entry_level);
+    std::vector<uint8_t> has1(1, 1);
+    std::vector<std::vector<Cand>> res;
+    for (uint32_t lc = search_level + 1; lc-- > 0;) {  // :284-290
+      rc = search_layer_batch(1, {current_nearest[0]}, has1, 1, lc, res);
+      if (rc) return rc;
+      if (!res[0].empty()) current_nearest = res[0];
+    }
+    for (uint32_t lc = 0; lc <= level; ++lc) {  // :293-362
+      const uint32_t m = cap(lc);
+      const Cand start = (lc <= search_level && !current_nearest.empty()) ? current_nearest[0] : Cand{ep, d0[0]};
+      rc = search_layer_batch(1, {start}, has1, cfg_.ef_construction, lc, res);
+      if (rc) return rc;
+      std::vector<uint32_t> chosen;  // select_neighbors :556-558
+      for (size_t i = 0; i < res[0].size() && i < m; ++i) chosen.push_back(res[0][i].node);
+      for (uint32_t nbv : chosen) set_insert(nbrs_[row][lc], nbv);
+      std::vector<uint32_t> to_prune;
+      for (uint32_t nbv : chosen) {
+        if (!registered_[nbv]) continue;
+        if (level_[nbv] >= lc) {
+          set_insert(nbrs_[nbv][lc], row);
+          if (nbrs_[nbv][lc].size() > m) to_prune.push_back(nbv);
+        }
+      }
+      for (uint32_t nbv : to_prune) {  // prune_neighbors_with_new_node :588-624
+        const std::vector<uint32_t> list = nbrs_[nbv][lc];
+        std::vector<float> ds;
+        rc = score_pairs_from_row(nbv, list, ds);
+        if (rc) return rc;
+        std::vector<Cand> cs(list.size());
+        for (size_t i = 0; i < list.size(); ++i) cs[i] = {list[i], ds[i]};
+        std::stable_sort(cs.begin(), cs.end(), [](const Cand& a, const Cand& c) { return a.distance < c.distance; });
+        if (cs.size() > m) cs.resize(m);
+        nbrs_[nbv][lc].clear();
+        for (const Cand& c : cs) set_insert(nbrs_[nbv][lc], c.node);
+      }
+      if (!to_prune.empty()) {  // put the new vector back as the query for the next layer
+        rc = fvdb_scorer_set_query_rows(scorer_, &row, 1);
+        if (rc) return rc;
+      }
+    }
+  }
+  index_of_[id] = row;
+  registered_[row] = 1;
+  n_registered_ += 1;
+  if (!is_first && level > entry_level) entry_ = row;  // :372-375
+  return FVDB_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// graph install / export, bulk build
+// --------------------------------------------------------------------------------------------
+int HNSWIndex::restore(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const uint32_t* levels,
+                       const uint64_t* nbr_offsets, const uint64_t* nbrs, uint64_t entry_id) {
+  if (!ids_.empty()) return FVDB_E_INVALID;
+  if (n == 0) return FVDB_OK;
+  dim_ = dim;
+  has_dim_ = true;
+  int rc = ensure_store(dim);
+  if (rc) return rc;
+  uint64_t first = 0;
+  rc = fvdb_store_append(store_, v, n, &first);
+  if (rc) return rc;
+  host_vecs_.assign(v, v + n * dim);
+  ids_.assign(ids, ids + n);
+  level_.assign(levels, levels + n);
+  deleted_.assign(n, 0);
+  registered_.assign(n, 1);
+  n_registered_ = n;
+  index_of_.reserve(n * 2);
+  for (uint64_t i = 0; i < n; ++i) index_of_[ids[i]] = (uint32_t)i;
+  nbrs_.assign(n, {});
+  uint64_t slot = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    nbrs_[i].resize(levels[i] + 1);
+    for (uint32_t l = 0; l <= levels[i]; ++l, ++slot) {
+      auto& s = nbrs_[i][l];
+      for (uint64_t e = nbr_offsets[slot]; e < nbr_offsets[slot + 1]; ++e) {
+        auto it = index_of_.find(nbrs[e]);
+        if (it == index_of_.end()) return FVDB_E_NOT_FOUND;
+        s.push_back(it->second);
+      }
+    }
+  }
+  auto it = index_of_.find(entry_id);
+  if (it == index_of_.end()) return FVDB_E_NOT_FOUND;
+  entry_ = it->second;
+  has_entry_ = true;
+  return FVDB_OK;
+}
+
+uint64_t HNSWIndex::graph_slots() const {
+  uint64_t s = 0;
+  for (size_t i = 0; i < ids_.size(); ++i) s += level_[i] + 1;
+  return s;
+}
+uint64_t HNSWIndex::graph_edges() const {
+  uint64_t e = 0;
+  for (const auto& n : nbrs_)
+    for (const auto& l : n) e += l.size();
+  return e;
+}
+void HNSWIndex::export_graph(uint64_t* ids, uint32_t* levels, uint64_t* nbr_offsets, uint64_t* nbrs) const {
+  uint64_t slot = 0, e = 0;
+  for (size_t i = 0; i < ids_.size(); ++i) {
+    ids[i] = ids_[i];
+    levels[i] = level_[i];
+    for (uint32_t l = 0; l <= level_[i]; ++l, ++slot) {
+      nbr_offsets[slot] = e;
+      for (uint32_t x : nbrs_[i][l]) nbrs[e++] = ids_[x];
+    }
+  }
+  nbr_offsets[slot] = e;
+}
+
+int HNSWIndex::bulk_build(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const int64_t* levels) {
+  if (!ids_.empty()) return FVDB_E_INVALID;
+  if (n == 0) return FVDB_OK;
+  if (n >= 0xFFFFFFFFull) return FVDB_E_UNSUPPORTED;
+  {
+    std::unordered_set<uint64_t> seen;
+    seen.reserve(n * 2);
+    for (uint64_t i = 0; i < n; ++i)
+      if (!seen.insert(ids[i]).second) return FVDB_E_DUPLICATE;
+  }
+  dim_ = dim;
+  has_dim_ = true;
+  int rc = ensure_store(dim);
+  if (rc) return rc;
+  uint64_t first = 0;
+  rc = fvdb_store_append(store_, v, n, &first);
+  if (rc) return rc;
+  host_vecs_.assign(v, v + n * dim);
+  ids_.assign(ids, ids + n);
+  level_.resize(n);
+  uint32_t maxlevel = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    level_[i] = levels ? (uint32_t)levels[i] : (uint32_t)assign_level();
+    maxlevel = std::max(maxlevel, level_[i]);
+  }
+  deleted_.assign(n, 0);
+  registered_.assign(n, 1);
+  n_registered_ = n;
+  index_of_.reserve(n * 2);
+  for (uint64_t i = 0; i < n; ++i) index_of_[ids[i]] = (uint32_t)i;
+  nbrs_.assign(n, {});
+  for (uint64_t i = 0; i < n; ++i) nbrs_[i].resize(level_[i] + 1);
+  // entry = earliest node carrying the maximum level (what sequential insertion ends with, :372-375)
+  for (uint64_t i = 0; i < n; ++i)
+    if (level_[i] == maxlevel) {
+      entry_ = (uint32_t)i;
+      break;
+    }
+  has_entry_ = true;
+
+  std::vector<float> zero(dim, 0.0f);
+  for (uint32_t l = 0; l <= maxlevel; ++l) {
+    std::vector<uint32_t> members;
+    for (uint64_t i = 0; i < n; ++i)
+      if (level_[i] >= l) members.push_back((uint32_t)i);
+    if (members.size() < 2) continue;
+    const uint32_t kk = (uint32_t)std::min<uint64_t>(cap(l), members.size() - 1);
+    const uint32_t k = kk + 1;  // the member itself comes back at distance 0
+    if (k > FVDB_MAX_K) return FVDB_E_UNSUPPORTED;
+    fvdb_ivf* flat = nullptr;
+    rc = fvdb_ivf_create(ctx_, dim, 1, &flat);
+    if (rc) return rc;
+    rc = fvdb_ivf_set_centroids(flat, zero.data());
+    std::vector<float> mv;
+    std::vector<uint64_t> mid(members.size());
+    std::vector<uint32_t> mcl(members.size(), 0);
+    const float* src = v;
+    if (rc == FVDB_OK && members.size() != n) {
+      mv.resize(members.size() * (size_t)dim);
+      for (size_t j = 0; j < members.size(); ++j)
+        std::memcpy(&mv[j * dim], v + (size_t)members[j] * dim, dim * sizeof(float));
+      src = mv.data();
+    }
+    for (size_t j = 0; j < members.size(); ++j) mid[j] = members[j];
+    if (rc == FVDB_OK) rc = fvdb_ivf_add_assigned(flat, src, mid.data(), members.size(), mcl.data(), nullptr);
+    const uint32_t step = 16384;
+    std::vector<uint64_t> oi((size_t)step * k);
+    std::vector<float> od((size_t)step * k);
+    std::vector<uint32_t> oc(step);
+    for (size_t o = 0; rc == FVDB_OK && o < members.size(); o += step) {
+      const uint32_t b = (uint32_t)std::min<size_t>(step, members.size() - o);
+      rc = fvdb_ivf_search_all(flat, src + o * dim, b, k, oi.data(), od.data(), oc.data());
+      if (rc) break;
+      for (uint32_t i = 0; i < b; ++i) {
+        const uint32_t self = members[o + i];
+        auto& s = nbrs_[self][l];
+        for (uint32_t e = 0; e < oc[i] && s.size() < kk; ++e) {
+          const uint32_t nbv = (uint32_t)oi[(size_t)i * k + e];
+          if (nbv != self) s.push_back(nbv);
+        }
+      }
+    }
+    fvdb_ivf_destroy(flat);
+    if (rc) return rc;
+  }
+  return FVDB_OK;
+}
+
+}  // namespace fvdbh

@@ -1,0 +1,189 @@
+// hybrid_index.cpp — HybridIndex mirror (src/hybrid/core.rs): age routing, per-search
+// auto-migration, HNSW + IVF search and the stable merge.
+#include <algorithm>
+#include <cstring>
+
+#include "fvdb_host.hpp"
+
+namespace fvdbh {
+
+HybridIndex::HybridIndex(fvdb_ctx* ctx_ivf, fvdb_ctx* ctx_hnsw, const HybridConfig& cfg) : cfg_(cfg) {
+  recent_ = new HNSWIndex(ctx_hnsw, cfg.hnsw);
+  historical_ = new IVFIndex(ctx_ivf, cfg.ivf);
+}
+
+HybridIndex::~HybridIndex() {
+  delete recent_;
+  delete historical_;
+}
+
+// src/hybrid/core.rs:262-290
+int HybridIndex::initialize(const float* data, uint64_t n, uint32_t dim) {
+  if (n < cfg_.min_ivf_training_size) {  // HNSW-only mode
+    ivf_trained_ = false;
+    initialized_ = true;
+    return FVDB_OK;
+  }
+  int rc = historical_->train(data, n, dim, nullptr);
+  if (rc) return rc;
+  historical_->clear_lists();  // :278-287
+  ivf_trained_ = true;
+  initialized_ = true;
+  return FVDB_OK;
+}
+
+int HybridIndex::set_ivf_centroids(const float* c, uint32_t dim) {
+  int rc = historical_->set_trained(c, dim);
+  if (rc) return rc;
+  ivf_trained_ = true;
+  initialized_ = true;
+  return FVDB_OK;
+}
+
+// src/hybrid/core.rs:357-417
+int HybridIndex::insert_with_timestamp(uint64_t id, const float* v, uint32_t dim, double ts, double now,
+                                       int64_t level) {
+  if (!initialized_) return FVDB_E_NOT_INITIALIZED;
+  if (timestamps_.count(id)) return FVDB_E_DUPLICATE;
+  bool to_recent = !ivf_trained_ || age_of(now, ts) < cfg_.recent_threshold_s;
+  if (to_recent) {
+    int rc = recent_->insert(id, v, dim, level);
+    if (rc) return rc;
+    recent_count_ += 1;
+    pending_migration_.push_back(id);
+  } else {
+    int rc = historical_->insert(id, v, dim);
+    if (rc) return rc;
+    historical_count_ += 1;
+  }
+  timestamps_[id] = ts;
+  ts_order_.push_back(id);
+  return FVDB_OK;
+}
+
+// Scale loader: same routing as insert_with_timestamp, but the HNSW part is bulk-built and the
+// IVF part is assigned/appended in one GPU pass.  Only valid on an index with no vectors yet.
+int HybridIndex::bulk_insert(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const double* ts,
+                             double now) {
+  if (!initialized_) return FVDB_E_NOT_INITIALIZED;
+  if (!ts_order_.empty()) return FVDB_E_INVALID;
+  std::vector<uint64_t> rid, hid;
+  std::vector<float> rv, hv;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (timestamps_.count(ids[i])) return FVDB_E_DUPLICATE;
+    timestamps_[ids[i]] = ts[i];
+    const bool to_recent = !ivf_trained_ || age_of(now, ts[i]) < cfg_.recent_threshold_s;
+    auto& I = to_recent ? rid : hid;
+    auto& V = to_recent ? rv : hv;
+    I.push_back(ids[i]);
+    V.insert(V.end(), v + i * dim, v + (i + 1) * dim);
+  }
+  ts_order_.assign(ids, ids + n);
+  if (!rid.empty()) {
+    int rc = recent_->bulk_build(rid.data(), rv.data(), rid.size(), dim, nullptr);
+    if (rc) return rc;
+    recent_count_ = rid.size();
+    pending_migration_ = rid;
+  }
+  if (!hid.empty()) {
+    uint64_t ok = 0;
+    int err = 0;
+    int rc = historical_->batch_insert(hid.data(), hv.data(), hid.size(), dim, &ok, &err);
+    if (rc) return rc;
+    if (err) return err;
+    historical_count_ = ok;
+  }
+  return FVDB_OK;
+}
+
+// src/hybrid/core.rs:600-649 — copies into IVF, never removes from HNSW (:577-581)
+uint64_t HybridIndex::migrate_with_threshold(double threshold_s, double now) {
+  if (pending_migration_.empty()) return 0;
+  std::vector<uint64_t> due, keep;
+  for (uint64_t id : pending_migration_) {
+    if (age_of(now, timestamps_[id]) >= threshold_s) due.push_back(id); else keep.push_back(id);
+  }
+  if (due.empty()) return 0;
+  uint64_t migrated = 0;
+  const uint32_t dim = recent_->dimension();
+  std::vector<float> xv;
+  std::vector<uint64_t> xi;
+  for (uint64_t id : due) {
+    const float* vec = recent_->vector_of(id);
+    if (!vec) continue;  // get_node(id) == None
+    xi.push_back(id);
+    xv.insert(xv.end(), vec, vec + dim);
+  }
+  if (!xi.empty()) {
+    int err = 0;
+    int rc = historical_->batch_insert(xi.data(), xv.data(), xi.size(), dim, &migrated, &err);
+    if (rc) return 0;  // IVF untrained / dimension mismatch: every insert fails; ids stay pending
+  }
+  // A copy that failed as a duplicate fails the same way on every later search (the reference
+  // retries it each time with no effect), so due ids leave the queue either way.
+  pending_migration_.swap(keep);
+  if (migrated) {
+    recent_count_ = recent_count_ >= migrated ? recent_count_ - migrated : 0;
+    historical_count_ += migrated;
+  }
+  return migrated;
+}
+
+// src/hybrid/core.rs:425-486 for a batch of queries
+int HybridIndex::search(const float* q, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg, double now,
+                        uint64_t* ids, float* dist, uint32_t* counts) {
+  const uint32_t k = (uint32_t)cfg.k;
+  for (uint32_t b = 0; b < B; ++b) counts[b] = 0;
+  for (size_t i = 0; i < (size_t)B * k; ++i) {
+    ids[i] = FVDB_NO_ID;
+    dist[i] = __builtin_huge_valf();
+  }
+  if (!initialized_ || B == 0 || k == 0) return FVDB_OK;
+  if (cfg_.auto_migrate) migrate_with_threshold(cfg_.recent_threshold_s, now);
+  const uint32_t rk = (uint32_t)(cfg.recent_k > 0 ? cfg.recent_k : cfg.k);
+  const uint32_t hk = (uint32_t)(cfg.historical_k > 0 ? cfg.historical_k : cfg.k);
+  std::vector<uint64_t> rid, hid;
+  std::vector<float> rd, hd;
+  std::vector<uint32_t> rc_(B, 0), hc(B, 0);
+  bool have_r = false, have_h = false;
+  if (cfg.search_historical && ivf_trained_) {
+    hid.resize((size_t)B * hk);
+    hd.resize((size_t)B * hk);
+    have_h = historical_->search(q, B, dim, hk, (uint32_t)cfg.ivf_n_probe, hid.data(), hd.data(), hc.data()) == FVDB_OK;
+  }
+  if (cfg.search_recent) {
+    rid.resize((size_t)B * rk);
+    rd.resize((size_t)B * rk);
+    have_r = recent_->search(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, rid.data(), rd.data(), rc_.data()) == FVDB_OK;
+  }
+  struct R {
+    uint64_t id;
+    float d;
+  };
+  std::vector<R> all;
+  for (uint32_t b = 0; b < B; ++b) {
+    all.clear();
+    if (have_r)
+      for (uint32_t i = 0; i < rc_[b]; ++i) all.push_back({rid[(size_t)b * rk + i], rd[(size_t)b * rk + i]});
+    if (have_h)
+      for (uint32_t i = 0; i < hc[b]; ++i) all.push_back({hid[(size_t)b * hk + i], hd[(size_t)b * hk + i]});
+    std::stable_sort(all.begin(), all.end(), [](const R& a, const R& c) { return a.d < c.d; });  // :482
+    if (all.size() > k) all.resize(k);
+    for (size_t i = 0; i < all.size(); ++i) {
+      ids[(size_t)b * k + i] = all[i].id;
+      dist[(size_t)b * k + i] = all[i].d;
+    }
+    counts[b] = (uint32_t)all.size();
+  }
+  return FVDB_OK;
+}
+
+// delete: src/hybrid/core.rs:904-937
+int HybridIndex::remove(uint64_t id, double now) {
+  auto it = timestamps_.find(id);
+  if (it == timestamps_.end()) return FVDB_E_NOT_FOUND;
+  if (age_of(now, it->second) < cfg_.recent_threshold_s) return recent_->mark_deleted(id);
+  return historical_->mark_deleted(id);
+}
+
+}  // namespace fvdbh
