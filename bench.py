@@ -1,0 +1,327 @@
+#!/usr/bin/env python
+"""bench.py — k-NN queries/sec at recall@10 >= 0.95 on the BASELINE.json headline workload.
+
+Workload (config.workload "c3"): 1M x 384 f32, hybrid HNSW/IVF (30 % recent -> HNSW, 70 %
+historical -> IVF-flat nlist 1024, inserted in 10K-vector chunks), batch = 1024 queries, k = 10.
+One "step" = one batch of 1024 queries through HybridIndex.search (auto-migration check, IVF
+coarse + list scan + top-k on the GPU, HNSW traversal on the host with every hop's candidate
+batch scored on the GPU, stable merge).  Query batches are resident in HBM before the timed
+region starts; results return to host memory (the reference API returns them to the caller).
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`:
+IVF lists are sharded over the ranks (every rank scans the probed lists it owns for ALL queries,
+per-rank partial top-k are all-gathered over RCCL and merged by key), the HNSW graph is replicated
+and its queries are split over the ranks; total work is fixed => "scaling": "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+"roofline" (dominant kernel = the list-scan kernel, timed with HIP events on its stream) and
+"cpu_baseline" (the CPU oracle = the reference algorithm restated, timed on this box's host cores
+on a bounded sample of the same queries; it is only the checker/baseline, never the product path).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DAY = 86400.0
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic data: latent Gaussian mixture embedded in d dims (see DESIGN.md "Synthetic data")
+# ------------------------------------------------------------------------------------------------
+class Generator:
+    """rows = (mean[c] + N(0, I_L)) @ P + ambient * N(0, I_d); means ~ spread * N(0, I_L), P: L x d orthonormal.
+    Counter-based Philox streams keyed by (seed, chunk) so any rank can regenerate any chunk."""
+
+    def __init__(self, d=384, latent=32, n_comp=4096, spread=1.5, ambient=0.02, seed=1234):
+        self.d, self.L, self.n_comp, self.ambient, self.seed = d, latent, n_comp, ambient, seed
+        r = np.random.Generator(np.random.Philox(key=seed))
+        self.means = (np.float32(spread) * r.standard_normal((n_comp, latent))).astype(np.float32)
+        qmat, _ = np.linalg.qr(r.standard_normal((d, latent)))
+        self.P = np.ascontiguousarray(qmat.T.astype(np.float32))  # L x d, orthonormal rows
+
+    def rows(self, n, stream):
+        r = np.random.Generator(np.random.Philox(key=self.seed + 1000003 * (stream + 1)))
+        comp = r.integers(0, self.n_comp, n)
+        z = self.means[comp] + r.standard_normal((n, self.L), dtype=np.float32)
+        x = z @ self.P
+        if self.ambient:
+            x += np.float32(self.ambient) * r.standard_normal((n, self.d), dtype=np.float32)
+        return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def usable_cpus():
+    """CPUs this process may use: min(affinity, cgroup quota) — the GPU box shows 256 and grants 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def recall_at_k(found_ids, found_cnt, exact_ids, k):
+    hits = 0
+    for b in range(found_ids.shape[0]):
+        hits += len(set(found_ids[b, : found_cnt[b]].tolist()) & set(exact_ids[b, :k].tolist()))
+    return hits / (k * found_ids.shape[0])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=384)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--nlist", type=int, default=1024)
+    ap.add_argument("--nprobe", type=int, default=0, help="0 = smallest of the sweep reaching the recall target")
+    ap.add_argument("--ef", type=int, default=0, help="0 = smallest of the sweep reaching the recall target")
+    ap.add_argument("--recent-frac", type=float, default=0.3)
+    ap.add_argument("--recall-target", type=float, default=0.95)
+    ap.add_argument("--train-sample", type=int, default=50_000)
+    ap.add_argument("--query-batches", type=int, default=4)
+    ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latent", type=int, default=32)
+    ap.add_argument("--spread", type=float, default=1.5)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    dist = None
+    torch = None
+    if world > 1:
+        import torch  # noqa: F811  (first, so this process uses one HIP runtime)
+        import torch.distributed as dist  # noqa: F811
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import fvdb_import
+    fv = fvdb_import.load()
+
+    N, d, B, k = args.n, args.dim, args.batch, args.k
+    now = 1000 * DAY
+    t_setup = time.time()
+    gen = Generator(d=d, latent=args.latent, spread=args.spread)
+    chunk = 10_000  # the reference's storage chunk (src/hybrid/persistence.rs:189) = our generation/insert unit
+    x = np.empty((N, d), np.float32)
+    for c in range(0, N, chunk):
+        x[c:c + chunk] = gen.rows(min(chunk, N - c), stream=c // chunk)
+    ids = np.arange(N, dtype=np.uint64)
+    r = np.random.Generator(np.random.Philox(key=99))
+    is_recent = r.random(N) < args.recent_frac
+    ts = np.where(is_recent, now - 1 * DAY, now - 30 * DAY)
+    nb = max(1, args.query_batches)
+    queries = [gen.rows(B, stream=10_000_000 + i) for i in range(nb)]
+    log(f"data: {N} x {d} generated in {time.time() - t_setup:.1f}s; recent={int(is_recent.sum())}")
+
+    ctx_ivf = fv.Context(local_rank)
+    ctx_hnsw = fv.Context(local_rank)
+    hyb = fv.HybridIndex(ctx_ivf, ctx_hnsw=ctx_hnsw, n_clusters=args.nlist, n_probe=min(32, args.nlist),
+                         train_size=args.train_sample, max_iterations=25, ivf_seed=7, hnsw_seed=11)
+    t0 = time.time()
+    sample = x[np.random.Generator(np.random.Philox(key=5)).choice(N, min(args.train_sample, N), replace=False)]
+    hyb.initialize(sample)
+    log(f"IVF k-means ({args.nlist} lists on {sample.shape[0]} rows, GPU): {time.time() - t0:.1f}s")
+
+    # ---- placement: single GPU = everything; multi GPU = lists sharded, HNSW replicated ----
+    t0 = time.time()
+    sharded = None
+    if world == 1:
+        hyb.bulk_insert(ids, x, ts, now)
+    else:
+        from fabstir_vectordb_amd import sharded as sh
+        sharded = sh.ShardedHybrid(fv, hyb, rank, world, dist, torch)
+        sharded.bulk_insert(ids, x, ts, now)
+    log(f"index build (HNSW bulk graph {hyb.recent_count()} nodes + IVF {hyb.historical_count()} rows): "
+        f"{time.time() - t0:.1f}s")
+
+    # ---- exact ground truth on the GPU (flat scan of all N rows) ----
+    t0 = time.time()
+    flat = fv.DeviceIVF(ctx_ivf, d, 1)
+    flat.set_centroids(np.zeros((1, d), np.float32))
+    for c in range(0, N, 200_000):
+        flat.add_assigned(x[c:c + 200_000], ids[c:c + 200_000], np.zeros(min(200_000, N - c), np.uint32))
+    exact = [flat.search_all(q, k)[0] for q in queries]
+    flat.close()
+    log(f"exact ground truth: {time.time() - t0:.1f}s")
+
+    qdev = [ctx_ivf.upload(q) for q in queries]
+
+    def run(i, nprobe, ef):
+        if sharded is not None:
+            return sharded.search_dev(qdev[i % nb], queries[i % nb], B, k, now, ef, nprobe)
+        return hyb.search_dev(qdev[i % nb], B, k, now=now, hnsw_ef=ef, ivf_n_probe=nprobe, dim=d)
+
+    # ---- operating point: smallest (nprobe, ef) of the sweep with recall@k >= target ----
+    sweep = []
+    nprobe, ef = args.nprobe, args.ef
+    if nprobe == 0 or ef == 0:
+        chosen = None
+        for e_ in ([ef] if ef else [50, 100, 200]):
+            for p_ in ([nprobe] if nprobe else [8, 16, 24, 32, 48, 64, 96, 128]):
+                p_ = min(p_, args.nlist)
+                res = run(0, p_, e_)
+                rec = recall_at_k(res.ids, res.counts, exact[0], k)
+                if rec >= args.recall_target:  # confirm on every query batch before accepting
+                    rec = float(np.mean([rec] + [recall_at_k(*(lambda r_: (r_.ids, r_.counts))(run(i, p_, e_)), exact[i], k)
+                                                 for i in range(1, nb)]))
+                sweep.append({"nprobe": p_, "ef": e_, "recall": round(rec, 4)})
+                log(f"sweep nprobe={p_} ef={e_}: recall@{k}={rec:.4f}")
+                if rec >= args.recall_target and chosen is None:
+                    chosen = (p_, e_)
+                    break
+            if chosen:
+                break
+        if chosen is None:
+            chosen = (sweep[-1]["nprobe"], sweep[-1]["ef"])
+            log("WARNING: recall target not reached in the sweep; using the largest setting")
+        nprobe, ef = chosen
+    log(f"operating point: nprobe={nprobe} ef={ef}")
+
+    # ---- timed region ----
+    for i in range(args.warmup):
+        run(i, nprobe, ef)
+    log("warmup done")
+    ctx_ivf.set_profiling(2)
+    hyb.ivf_device_stage_times()  # reset accumulators
+    hnsw = hyb.hnsw()
+    evals0, hops0 = hnsw.dist_evals(), hnsw.hops()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    ctx_ivf.synchronize()
+    ctx_hnsw.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = run(i, nprobe, ef)
+    ctx_ivf.synchronize()
+    ctx_hnsw.synchronize()
+    if dist is not None:
+        torch.cuda.synchronize()
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    log(f"timed region done: {elapsed:.3f}s")
+    if dist is not None:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ctx_ivf.set_profiling(0)
+    n_prof, stage = hyb.ivf_device_stage_times()
+    stats = hyb.ivf_device_last_stats()
+    evals, hops = hnsw.dist_evals() - evals0, hnsw.hops() - hops0
+
+    recs = []
+    for i in range(nb):
+        res = run(i, nprobe, ef)
+        recs.append(recall_at_k(res.ids, res.counts, exact[i], k))
+    recall = float(np.mean(recs))
+    qps = B * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    log(f"{args.steps} steps: {ms_per_step:.3f} ms/step, {qps:.0f} QPS, recall@{k}={recall:.4f}")
+
+    # ---- roofline of the dominant kernel (list scan) ----
+    scan_ms = stage["fine_scan"] / max(n_prof, 1)
+    alg_bytes = stats["rows_scanned"] * d * 4  # rows each query's probed lists hold x row bytes
+    achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+        "frac": round(achieved / 8000.0, 4), "traffic": None,
+        "kernel": "scan_topk_kernel<16,1> (IVF list scan)", "kernel_ms": round(scan_ms, 4),
+        "algorithmic_bytes_per_launch": int(alg_bytes),
+        "rows_scanned_per_query": round(stats["rows_scanned"] / B, 1),
+        "physical_lower_bound_bytes_per_launch": int(stats["list_rows_touched"] * d * 4),
+        "pair_dims_per_s": round(stats["rows_scanned"] * d / (scan_ms * 1e-3), 1) if scan_ms > 0 else 0.0,
+        "valu_lane_ops_frac_of_measured_peak": round(3 * stats["rows_scanned"] * d / (scan_ms * 1e-3) / 65.9e12, 4)
+        if scan_ms > 0 else 0.0,
+        "note": "queries probing the same list share one read of it, so algorithmic bytes/s can exceed the HBM "
+                "peak; the kernel is bound by f32 VALU issue (3 exact ops per pair-dim), see DESIGN.md",
+        "stage_ms": {k_: round(v / max(n_prof, 1), 4) for k_, v in stage.items()},
+        "hnsw": {"hops_per_step": round(hops / args.steps, 1), "dist_evals_per_query": round(evals / args.steps / B, 1)},
+    }
+
+    # ---- CPU baseline: the oracle (reference algorithm restated) on the same structures ----
+    cpu = None
+    if not args.no_cpu_baseline and rank == 0:
+        cpu = cpu_baseline(fv, hyb, sharded, x, ids, is_recent, ts, now, queries[0], last if nb == 1 else run(0, nprobe, ef),
+                           k, nprobe, ef, args)
+
+    if rank == 0:
+        out = {
+            "metric": "k-NN queries/sec at recall@10>=0.95, 1Mx384 f32",
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "c3: 1M x 384 f32 hybrid HNSW/IVF (10K-vector chunks), batch 1024, k 10",
+                       "n_vectors": N, "dim": d, "batch": B, "k": k, "recent_frac_hnsw": args.recent_frac,
+                       "nlist": args.nlist, "nprobe": nprobe, "hnsw_ef": ef, "hnsw_M": 16, "hnsw_M0": 32,
+                       "recall_at_10": round(recall, 4), "recall_target": args.recall_target, "sweep": sweep,
+                       "generator": f"gaussian mixture: 4096 comps, means {args.spread}*N(0,I) in a rank-{args.latent} latent space, "
+                                    f"unit within-comp sigma, orthonormal embedding into {d}-d + 0.02 ambient noise",
+                       "parallelism": "1 gpu" if world == 1 else f"ivf lists sharded x{world} + allgather, hnsw queries split x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(fv, hyb, sharded, x, ids, is_recent, ts, now, q0, gpu_res, k, nprobe, ef, args):
+    """Times the CPU oracle on a bounded sample and checks the GPU results against it."""
+    import oracle as orc
+    orc.build()
+    t0 = time.time()
+    threads = usable_cpus()
+    o = orc.HybridIndex(n_clusters=args.nlist, n_probe=min(32, args.nlist))
+    o.set_ivf_centroids(hyb.ivf().get_centroids())
+    hist = ~is_recent
+    hx, hid = x[hist], ids[hist]
+    clusters = hyb.ivf().assign(hx)  # the GPU's find_nearest_centroid (parity-tested against the oracle's)
+    o.ivf().batch_insert_assigned(hid, hx, clusters)
+    gi, lv, off, nb_ = hyb.hnsw().export_graph()
+    oh = o.hnsw()
+    oh.restore(gi, x[gi.astype(np.int64)], lv, off, nb_, hyb.hnsw().entry_point())
+    setup_s = time.time() - t0
+    ns = min(args.cpu_sample, q0.shape[0])
+    t0 = time.perf_counter()
+    oi1, od1, oc1 = o.batch_search(q0[: max(8, ns // 8)], k, now=now, hnsw_ef=ef, ivf_n_probe=nprobe, threads=1)
+    t1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oi, od, oc = o.batch_search(q0[:ns], k, now=now, hnsw_ef=ef, ivf_n_probe=nprobe, threads=threads)
+    tall = time.perf_counter() - t0
+    same = bool(np.array_equal(oc, gpu_res.counts[:ns]) and np.array_equal(oi, gpu_res.ids[:ns]) and
+                np.array_equal(od.view(np.uint32), gpu_res.distances[:ns].view(np.uint32))) if sharded is None else None
+    log(f"cpu baseline: setup {setup_s:.1f}s; 1 thread {max(8, ns // 8) / t1:.1f} q/s; {threads} threads {ns / tall:.1f} q/s; "
+        f"gpu==oracle on the sample: {same}")
+    return {"value": round(ns / tall, 2), "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": f"{ns} queries of the first batch, same index structures and (nprobe, ef); one query per thread",
+            "single_thread_value": round(max(8, ns // 8) / t1, 2), "gpu_matches_oracle_on_sample": same}
+
+
+if __name__ == "__main__":
+    main()

@@ -58,6 +58,7 @@ SIGNATURES = {
     "fvdb_ivf_coarse": (i32, [vp, f32p, u32, u32, u32p, f32p]),
     "fvdb_ivf_last_stats": (i32, [vp, C.POINTER(SearchStats)]),
     "fvdb_ivf_stage_times": (u64, [vp, f32p]),
+    "fvdb_ivf_profile_collect": (i32, [vp]),
     "fvdb_merge_keys_dev": (i32, [vp, vp, vp, u32, u32, u32, vp, vp, vp]),
     "fvdb_store_create": (i32, [vp, u32, u64, C.POINTER(vp)]),
     "fvdb_store_destroy": (None, [vp]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "fvdb_scorer_destroy": (None, [vp]),
     "fvdb_scorer_set_queries": (i32, [vp, f32p, u32]),
     "fvdb_scorer_set_query_rows": (i32, [vp, u32p, u32]),
+    "fvdb_scorer_set_queries_dev": (i32, [vp, vp, u32]),
     "fvdb_scorer_cand_buffer": (u32p, [vp]),
     "fvdb_scorer_dist_buffer": (f32p, [vp]),
     "fvdb_scorer_run": (i32, [vp, u32, u32]),

@@ -71,7 +71,7 @@ struct fvdb_ctx {
   int num_cus = 256;
   std::string err;
   HBuf h_stage;     // host->device staging for host-pointer entry points
-  bool profiling = false;
+  int profiling = 0;
 };
 
 #define HIPCHK(ctx, call)                                                                     \
@@ -158,7 +158,7 @@ struct fvdb_ivf {
   uint64_t total_rows = 0;
   uint32_t max_list_blocks = 0;
   bool table_dirty = true;
-  DBuf t_off, t_blocks, t_glob;  // device list table + logical (global) block counts
+  DBuf t_off, t_blocks, t_glob, t_len;  // device list table, logical (global) block counts, rows per list
   std::vector<uint32_t> glob_blocks_host;  // empty => local sizes
   bool glob_set = false;
 
@@ -167,6 +167,7 @@ struct fvdb_ivf {
   DBuf s_in, s_slots, s_ids, s_clusters, s_out_ids, s_out_dist, s_out_cnt, s_cdist;
   fvdb_search_stats last_stats{};
   float stage_ms[5] = {0, 0, 0, 0, 0};  // coarse scan, coarse merge, plan, fine scan, fine merge
+  bool pending_profile = false, pend_coarse = false, pend_fine = false, collecting = false;
   uint64_t stage_calls = 0;
   hipEvent_t sev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -263,6 +264,9 @@ int upload_table(fvdb_ivf* ivf) {
   if (!blocks.empty())
     HIPCHK(ctx, hipMemcpyAsync(ivf->t_blocks.p, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ivf->t_glob.p, glob.data(), glob.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, ivf->t_len.ensure((size_t)ivf->nlist * 4));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->t_len.p, ivf->list_len.data(), (size_t)ivf->nlist * 4, hipMemcpyHostToDevice,
+                             ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
   ivf->table_dirty = false;
   return FVDB_OK;
@@ -355,7 +359,7 @@ int run_fine(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t 
   hipLaunchKernelGGL(plan_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, probes, n,
                      ivf->s_cnt.as<uint32_t>());
   hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ivf->s_cnt.as<uint32_t>(),
-                     ivf->t_off.as<uint32_t>(), nlist, segb, Q, ivf->s_eoff.as<uint32_t>(),
+                     ivf->t_off.as<uint32_t>(), ivf->t_len.as<uint32_t>(), nlist, segb, Q, ivf->s_eoff.as<uint32_t>(),
                      ivf->s_ioff.as<uint32_t>(), ivf->s_fill.as<uint32_t>(), scal + 2, scal + 3,
                      (unsigned long long*)(scal + 4));
   hipLaunchKernelGGL(plan_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, probes, n, np,
@@ -390,6 +394,12 @@ int run_fine(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t 
 int finish_profile(fvdb_ivf* ivf, bool coarse, bool fine) {
   fvdb_ctx* ctx = ivf->ctx;
   if (!ctx->profiling) return FVDB_OK;
+  if (ctx->profiling == 2 && !ivf->collecting) {  // deferred: remember what to fold in later
+    ivf->pend_coarse = coarse;
+    ivf->pend_fine = fine;
+    ivf->pending_profile = true;
+    return FVDB_OK;
+  }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   float ms = 0;
   if (coarse) {
@@ -475,7 +485,7 @@ int fvdb_ctx_synchronize(fvdb_ctx* ctx) {
 void* fvdb_ctx_stream(fvdb_ctx* ctx) { return (void*)ctx->stream; }
 const char* fvdb_last_error(fvdb_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 int fvdb_ctx_set_profiling(fvdb_ctx* ctx, int on) {
-  ctx->profiling = on != 0;
+  ctx->profiling = on;
   return FVDB_OK;
 }
 
@@ -541,7 +551,7 @@ void fvdb_ivf_destroy(fvdb_ivf* ivf) {
   ivf->pool.release();
   ivf->cpool.release();
   DBuf* bufs[] = {&ivf->d_centroids_rm, &ivf->c_off, &ivf->c_blocks, &ivf->c_glob, &ivf->t_off, &ivf->t_blocks,
-                  &ivf->t_glob, &ivf->s_q, &ivf->s_cpart, &ivf->s_probes, &ivf->s_cnt, &ivf->s_fill, &ivf->s_eoff,
+                  &ivf->t_glob, &ivf->t_len, &ivf->s_q, &ivf->s_cpart, &ivf->s_probes, &ivf->s_cnt, &ivf->s_fill, &ivf->s_eoff,
                   &ivf->s_ioff, &ivf->s_entries, &ivf->s_part, &ivf->s_scalars, &ivf->s_ceoff, &ivf->s_cioff,
                   &ivf->s_in, &ivf->s_slots, &ivf->s_ids, &ivf->s_clusters, &ivf->s_out_ids, &ivf->s_out_dist,
                   &ivf->s_out_cnt, &ivf->s_cdist};
@@ -882,6 +892,15 @@ int fvdb_ivf_last_stats(fvdb_ivf* ivf, fvdb_search_stats* out) {
   out->work_items = st[1];
   out->list_rows_touched = st[2];
   return FVDB_OK;
+}
+
+int fvdb_ivf_profile_collect(fvdb_ivf* ivf) {
+  if (!ivf->pending_profile) return FVDB_OK;
+  ivf->collecting = true;
+  int rc = finish_profile(ivf, ivf->pend_coarse, ivf->pend_fine);
+  ivf->collecting = false;
+  ivf->pending_profile = false;
+  return rc;
 }
 
 // stage times accumulated while profiling is on: ms[5] = coarse scan, coarse merge, plan, fine scan,
@@ -1232,6 +1251,22 @@ int fvdb_scorer_set_query_rows(fvdb_scorer* sc, const uint32_t* rows, uint32_t B
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FVDB_OK;
+}
+
+int fvdb_scorer_set_queries_dev(fvdb_scorer* sc, const float* q_dev, uint32_t B) {
+  fvdb_store* s = sc->store;
+  fvdb_ctx* ctx = s->ctx;
+  if (B > sc->max_B) FAIL(ctx, FVDB_E_INVALID, "B above scorer capacity");
+  if (B == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (s->d == s->dpad) {
+    HIPCHK(ctx, hipMemcpyAsync(sc->d_q, q_dev, (size_t)B * s->d * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv((uint64_t)B * s->dpad, 256)), dim3(256), 0, ctx->stream, q_dev, s->d,
+                       s->dpad, (uint64_t)B, sc->d_q);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  return FVDB_OK;  // stream-ordered before the next fvdb_scorer_run on this context
 }
 
 uint32_t* fvdb_scorer_cand_buffer(fvdb_scorer* sc) { return sc->h_cand; }

@@ -151,21 +151,16 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(
     const uint32_t e0 = e_begin + g * Q;
     const uint32_t ne = min((uint32_t)Q, cnt - g * Q);
 
-    uint32_t qoff[Q], slot[Q];
+    uint32_t qoff[Q];
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
       const u32x2 e = cload(entries + e0 + ((uint32_t)j < ne ? j : 0));
       qoff[j] = e.x * dpad;
-      slot[j] = ((e.x * nprobe + e.y) * maxsegs + seg) * k;
     }
 
     WaveTopK<KR> tk[Q];
-    uint32_t th[Q], tl[Q];
 #pragma unroll
-    for (int j = 0; j < Q; ++j) {
-      tk[j].init();
-      th[j] = tl[j] = kInf32;
-    }
+    for (int j = 0; j < Q; ++j) tk[j].init();
 
     for (uint32_t b = b0; b < b1; ++b) {
       const uint32_t blk = cload(list_blocks + b_begin + b);
@@ -173,17 +168,22 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(
       float acc[Q];
 #pragma unroll
       for (int j = 0; j < Q; ++j) acc[j] = 0.0f;
+      float4 x = xp[0];
       for (uint32_t c = 0; c < d4; ++c) {
-        const float4 x = xp[(size_t)c * 64];
+        // next chunk's row data is in flight while this chunk is folded into Q running sums
+        const float4 xn = xp[(size_t)(c + 1 < d4 ? c + 1 : c) * 64];
+        f32x4 qv[Q];
+#pragma unroll
+        for (int j = 0; j < Q; ++j) qv[j] = cload((const f32x4*)(queries + qoff[j] + 4 * c));
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
-          const f32x4 qv = cload((const f32x4*)(queries + qoff[j] + 4 * c));
           float t;
-          t = x.x - qv.x; acc[j] = acc[j] + t * t;
-          t = x.y - qv.y; acc[j] = acc[j] + t * t;
-          t = x.z - qv.z; acc[j] = acc[j] + t * t;
-          t = x.w - qv.w; acc[j] = acc[j] + t * t;
+          t = x.x - qv[j].x; acc[j] = acc[j] + t * t;
+          t = x.y - qv[j].y; acc[j] = acc[j] + t * t;
+          t = x.z - qv[j].z; acc[j] = acc[j] + t * t;
+          t = x.w - qv[j].w; acc[j] = acc[j] + t * t;
         }
+        x = xn;
       }
       const uint64_t vmask = cload(pool_valid + blk);
       const bool live = (vmask >> lane) & 1ull;
@@ -192,21 +192,25 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(
       for (int j = 0; j < Q; ++j) {
         const float dist = sqrtf(acc[j]);
         const uint32_t chi = live ? __float_as_uint(dist) : kInf32;
-        offer<KR>(tk[j], k, chi, pos, th[j], tl[j], lane);
+        uint32_t th, tl;
+        tk[j].kth(k, th, tl);
+        offer<KR>(tk[j], k, chi, pos, th, tl, lane);
       }
     }
 
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
       if ((uint32_t)j < ne) {
+        const u32x2 e = cload(entries + e0 + j);
+        const uint32_t slot = ((e.x * nprobe + e.y) * maxsegs + seg) * k;
 #pragma unroll
         for (int r = 0; r < KR; ++r) {
-          const uint32_t e = r * 64 + lane;
-          if (e < k) {
+          const uint32_t el = r * 64 + lane;
+          if (el < k) {
             u32x2 v;
             v.x = tk[j].hi[r];
             v.y = tk[j].lo[r];
-            part[slot[j] + e] = v;
+            part[slot + el] = v;
           }
         }
       }
@@ -346,7 +350,8 @@ __global__ void plan_count_kernel(const uint32_t* __restrict__ probes, uint32_t 
 
 // single block of 1024 threads: exclusive scans over lists
 __global__ __launch_bounds__(1024) void plan_scan_kernel(const uint32_t* __restrict__ cnt,
-                                                         const uint32_t* __restrict__ list_off, uint32_t nlist,
+                                                         const uint32_t* __restrict__ list_off,
+                                                         const uint32_t* __restrict__ list_len, uint32_t nlist,
                                                          uint32_t segb, uint32_t Q, uint32_t* __restrict__ entry_off,
                                                          uint32_t* __restrict__ item_off, uint32_t* __restrict__ fill,
                                                          uint32_t* __restrict__ n_items, uint32_t* __restrict__ head,
@@ -370,8 +375,8 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const uint32_t* __restr
       it = (c == 0 || nblk == 0) ? 0u : nseg * ((c + Q - 1) / Q);
       fill[L] = 0;
       if (c) {
-        atomicAdd(&s_rows, (unsigned long long)c * nblk * 64ull);
-        atomicAdd(&s_touch, (unsigned long long)nblk * 64ull);
+        atomicAdd(&s_rows, (unsigned long long)c * list_len[L]);
+        atomicAdd(&s_touch, (unsigned long long)list_len[L]);
       }
     }
     s_e[t] = c;

@@ -159,6 +159,23 @@ int fvh_hybrid_search(void* p, const float* q, uint32_t B, uint32_t d, uint64_t 
   c.historical_k = historical_k;
   return ((HybridIndex*)p)->search(q, B, d, c, now, ids, dist, counts);
 }
+int fvh_hybrid_search_dev(void* p, const float* q_dev, uint32_t B, uint32_t d, uint64_t k, uint64_t ef, uint64_t nprobe,
+                          int search_recent, int search_historical, uint64_t recent_k, uint64_t historical_k,
+                          double now, uint64_t* ids, float* dist, uint32_t* counts) {
+  HybridSearchConfig c;
+  c.k = k;
+  c.hnsw_ef = ef;
+  c.ivf_n_probe = nprobe;
+  c.search_recent = search_recent != 0;
+  c.search_historical = search_historical != 0;
+  c.recent_k = recent_k;
+  c.historical_k = historical_k;
+  return ((HybridIndex*)p)->search_dev(q_dev, B, d, c, now, ids, dist, counts);
+}
+int fvh_hnsw_search_dev(void* p, const float* q_dev, uint32_t B, uint32_t d, uint32_t k, uint32_t ef, uint64_t* ids,
+                        float* dist, uint32_t* counts) {
+  return ((HNSWIndex*)p)->search_dev(q_dev, B, d, k, ef, ids, dist, counts);
+}
 int fvh_hybrid_delete(void* p, uint64_t id, double now) { return ((HybridIndex*)p)->remove(id, now); }
 uint64_t fvh_hybrid_migrate(void* p, double thr, double now) {
   return ((HybridIndex*)p)->migrate_with_threshold(thr, now);

@@ -85,6 +85,9 @@ class IVFIndex {
   int find_cluster(const float* v, uint32_t dim, uint32_t* out);                  // :493
   int search(const float* q, uint32_t B, uint32_t dim, uint32_t k, uint32_t n_probe, uint64_t* ids, float* dist,
              uint32_t* counts);                                                   // :626, operations.rs:132
+  // same with the queries already resident in HBM (B x d row-major); outputs are device pointers
+  int search_dev(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t n_probe, uint64_t* ids_dev,
+                 float* dist_dev, uint32_t* counts_dev);
   int mark_deleted(uint64_t id);                                                  // operations.rs:569
   bool is_deleted(uint64_t id) const { return deleted_.count(id) > 0; }
   uint64_t active_count() const { return total_ - deleted_.size(); }
@@ -128,6 +131,8 @@ class HNSWIndex {
   int insert(uint64_t id, const float* v, uint32_t dim, int64_t forced_level);     // :226
   int search(const float* q, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
              uint32_t* counts);                                                    // :398 (batched, lock-step hops)
+  int search_dev(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
+                 uint32_t* counts);  // queries resident in HBM, results to host
   int mark_deleted(uint64_t id);                                                   // operations.rs:127
   bool is_deleted(uint64_t id) const;
   uint64_t active_count() const;
@@ -165,6 +170,8 @@ class HNSWIndex {
   int search_layer_batch(uint32_t B, const std::vector<Cand>& entries, const std::vector<uint8_t>& has_entry,
                          uint32_t ef, uint32_t layer, std::vector<std::vector<Cand>>& results);
   int score_pairs_from_row(uint32_t base_row, const std::vector<uint32_t>& cands, std::vector<float>& out);
+  int search_impl(const float* q, bool q_on_device, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids,
+                  float* dist, uint32_t* counts);
 
   fvdb_ctx* ctx_;
   HNSWConfig cfg_;
@@ -224,6 +231,10 @@ class HybridIndex {
   int insert_with_timestamp(uint64_t id, const float* v, uint32_t dim, double ts, double now, int64_t level);  // :357
   int search(const float* q, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg, double now, uint64_t* ids,
              float* dist, uint32_t* counts);                                                       // :425
+  // queries resident in HBM: the IVF scan runs asynchronously on its own stream while the host walks
+  // the HNSW graph (hop scoring on the second stream); results come back to host memory
+  int search_dev(const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg, double now,
+                 uint64_t* ids, float* dist, uint32_t* counts);
   uint64_t migrate_with_threshold(double threshold_s, double now);                                // :600
   int remove(uint64_t id, double now);                                                             // delete :904
   uint64_t recent_count() const { return recent_count_; }
@@ -235,6 +246,11 @@ class HybridIndex {
 
  private:
   static double age_of(double now, double ts) { return now - ts < 0 ? 0.0 : now - ts; }
+  int search_impl(const float* q, bool q_on_device, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
+                  double now, uint64_t* ids, float* dist, uint32_t* counts);
+  fvdb_ctx* ctx_ivf_;
+  void *d_hid_ = nullptr, *d_hd_ = nullptr, *d_hc_ = nullptr;  // device result buffers of the IVF part
+  uint64_t d_cap_ = 0;
   HybridConfig cfg_;
   HNSWIndex* recent_;
   IVFIndex* historical_;

@@ -5,6 +5,8 @@
 #include <omp.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "fvdb_host.hpp"
@@ -95,6 +97,32 @@ bool Visited::insert(uint32_t v) {
     if (keys[h] == v) return false;
     h = (h + 1) & mask;
   }
+}
+
+// Worker threads for the lock-step traversal: the CPUs this process may actually use — the
+// smaller of its affinity mask and its cgroup CPU quota (a container can see 256 CPUs and own
+// 16; oversubscribed OpenMP barriers then collapse under CFS throttling).  FVDB_HOST_THREADS overrides.
+static int usable_cpus() {
+  if (const char* e = getenv("FVDB_HOST_THREADS")) {
+    int v = atoi(e);
+    if (v > 0) return v;
+  }
+  int n = omp_get_num_procs();
+  long quota = -1, period = -1;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+    char q[64];
+    if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+    fclose(f);
+  } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+    if (fscanf(f1, "%ld", &quota) != 1) quota = -1;
+    fclose(f1);
+    if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (fscanf(f2, "%ld", &period) != 1) period = -1;
+      fclose(f2);
+    }
+  }
+  if (quota > 0 && period > 0) n = std::min<long>(n, std::max<long>(1, (quota + period - 1) / period));
+  return std::max(1, std::min(n, 64));
 }
 
 static inline bool set_insert(std::vector<uint32_t>& s, uint32_t v) {
@@ -196,7 +224,8 @@ int HNSWIndex::search_layer_batch(uint32_t B, const std::vector<Cand>& entries, 
   const uint32_t maxC = scorer_C_;
   uint32_t* cand = fvdb_scorer_cand_buffer(scorer_);
   const float* dist = fvdb_scorer_dist_buffer(scorer_);
-  const int nt = threads_ > 0 ? threads_ : omp_get_max_threads();
+  static const int auto_threads = usable_cpus();
+  const int nt = threads_ > 0 ? threads_ : auto_threads;
   const bool par = B >= 32 && nt > 1;
   std::vector<uint32_t> prev_cnt(B, maxC);  // rows start dirty: clear them on first use
 
@@ -256,6 +285,8 @@ int HNSWIndex::search_layer_batch(uint32_t B, const std::vector<Cand>& entries, 
       hop_dists += n;
     }
     if (hopC == 0) break;
+    static const bool dbg = getenv("FVDB_DEBUG") != nullptr;
+    if (dbg && (n_hops_ % 50 == 0)) fprintf(stderr, "[hnsw] layer %u hop %llu C=%u dists=%llu\n", layer, (unsigned long long)n_hops_, hopC, (unsigned long long)hop_dists);
     int rc = fvdb_scorer_run(scorer_, B, hopC);
     if (rc) return rc;
     n_hops_ += 1;
@@ -292,6 +323,15 @@ int HNSWIndex::search_layer_batch(uint32_t B, const std::vector<Cand>& entries, 
 // --------------------------------------------------------------------------------------------
 int HNSWIndex::search(const float* q, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
                       uint32_t* counts) {
+  return search_impl(q, false, B, dim, k, ef, ids, dist, counts);
+}
+int HNSWIndex::search_dev(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids,
+                          float* dist, uint32_t* counts) {
+  return search_impl(q_dev, true, B, dim, k, ef, ids, dist, counts);
+}
+
+int HNSWIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef,
+                           uint64_t* ids, float* dist, uint32_t* counts) {
   for (uint32_t b = 0; b < B; ++b) counts[b] = 0;
   for (size_t i = 0; i < (size_t)B * k; ++i) {
     ids[i] = FVDB_NO_ID;
@@ -306,7 +346,8 @@ int HNSWIndex::search(const float* q, uint32_t B, uint32_t dim, uint32_t k, uint
     const uint32_t b = std::min(step, B - o);
     int rc = ensure_scorer(b, maxdeg);
     if (rc) return rc;
-    rc = fvdb_scorer_set_queries(scorer_, q + (size_t)o * dim, b);
+    rc = q_on_device ? fvdb_scorer_set_queries_dev(scorer_, q + (size_t)o * dim, b)
+                     : fvdb_scorer_set_queries(scorer_, q + (size_t)o * dim, b);
     if (rc) return rc;
     // nearest = [(entry, dist(q, entry))]  (:432-435): one hop with a single candidate
     uint32_t* cand = fvdb_scorer_cand_buffer(scorer_);

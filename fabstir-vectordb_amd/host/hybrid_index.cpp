@@ -1,18 +1,23 @@
 // hybrid_index.cpp — HybridIndex mirror (src/hybrid/core.rs): age routing, per-search
 // auto-migration, HNSW + IVF search and the stable merge.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "fvdb_host.hpp"
 
 namespace fvdbh {
 
-HybridIndex::HybridIndex(fvdb_ctx* ctx_ivf, fvdb_ctx* ctx_hnsw, const HybridConfig& cfg) : cfg_(cfg) {
+HybridIndex::HybridIndex(fvdb_ctx* ctx_ivf, fvdb_ctx* ctx_hnsw, const HybridConfig& cfg) : ctx_ivf_(ctx_ivf), cfg_(cfg) {
   recent_ = new HNSWIndex(ctx_hnsw, cfg.hnsw);
   historical_ = new IVFIndex(ctx_ivf, cfg.ivf);
 }
 
 HybridIndex::~HybridIndex() {
+  if (d_hid_) fvdb_dev_free(ctx_ivf_, d_hid_);
+  if (d_hd_) fvdb_dev_free(ctx_ivf_, d_hd_);
+  if (d_hc_) fvdb_dev_free(ctx_ivf_, d_hc_);
   delete recent_;
   delete historical_;
 }
@@ -132,6 +137,15 @@ uint64_t HybridIndex::migrate_with_threshold(double threshold_s, double now) {
 // src/hybrid/core.rs:425-486 for a batch of queries
 int HybridIndex::search(const float* q, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg, double now,
                         uint64_t* ids, float* dist, uint32_t* counts) {
+  return search_impl(q, false, B, dim, cfg, now, ids, dist, counts);
+}
+int HybridIndex::search_dev(const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg, double now,
+                            uint64_t* ids, float* dist, uint32_t* counts) {
+  return search_impl(q_dev, true, B, dim, cfg, now, ids, dist, counts);
+}
+
+int HybridIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
+                             double now, uint64_t* ids, float* dist, uint32_t* counts) {
   const uint32_t k = (uint32_t)cfg.k;
   for (uint32_t b = 0; b < B; ++b) counts[b] = 0;
   for (size_t i = 0; i < (size_t)B * k; ++i) {
@@ -146,16 +160,48 @@ int HybridIndex::search(const float* q, uint32_t B, uint32_t dim, const HybridSe
   std::vector<float> rd, hd;
   std::vector<uint32_t> rc_(B, 0), hc(B, 0);
   bool have_r = false, have_h = false;
+  static const bool dbg = getenv("FVDB_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "[hybrid] search B=%u k=%u dev=%d\n", B, k, (int)q_on_device);
+  bool ivf_in_flight = false;
   if (cfg.search_historical && ivf_trained_) {
     hid.resize((size_t)B * hk);
     hd.resize((size_t)B * hk);
-    have_h = historical_->search(q, B, dim, hk, (uint32_t)cfg.ivf_n_probe, hid.data(), hd.data(), hc.data()) == FVDB_OK;
+    if (!q_on_device) {
+      have_h = historical_->search(q, B, dim, hk, (uint32_t)cfg.ivf_n_probe, hid.data(), hd.data(), hc.data()) == FVDB_OK;
+    } else {
+      // enqueue the whole IVF search on its stream; it runs while the host walks the graph below
+      const uint64_t need = (uint64_t)B * hk;
+      if (need > d_cap_) {
+        if (d_hid_) fvdb_dev_free(ctx_ivf_, d_hid_);
+        if (d_hd_) fvdb_dev_free(ctx_ivf_, d_hd_);
+        if (d_hc_) fvdb_dev_free(ctx_ivf_, d_hc_);
+        d_hid_ = d_hd_ = d_hc_ = nullptr;
+        d_cap_ = 0;
+        if (fvdb_dev_alloc(ctx_ivf_, need * 8, &d_hid_) || fvdb_dev_alloc(ctx_ivf_, need * 4, &d_hd_) ||
+            fvdb_dev_alloc(ctx_ivf_, need * 4, &d_hc_))
+          return FVDB_E_OOM;
+        d_cap_ = need;
+      }
+      ivf_in_flight = historical_->search_dev(q, B, dim, hk, (uint32_t)cfg.ivf_n_probe, (uint64_t*)d_hid_,
+                                              (float*)d_hd_, (uint32_t*)d_hc_) == FVDB_OK;
+    }
   }
+  if (dbg) fprintf(stderr, "[hybrid] ivf enqueued (in flight=%d)\n", (int)ivf_in_flight);
   if (cfg.search_recent) {
     rid.resize((size_t)B * rk);
     rd.resize((size_t)B * rk);
-    have_r = recent_->search(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, rid.data(), rd.data(), rc_.data()) == FVDB_OK;
+    int rc2 = q_on_device ? recent_->search_dev(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, rid.data(), rd.data(), rc_.data())
+                          : recent_->search(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, rid.data(), rd.data(), rc_.data());
+    have_r = rc2 == FVDB_OK;
   }
+  if (dbg) fprintf(stderr, "[hybrid] hnsw done\n");
+  if (ivf_in_flight) {
+    have_h = fvdb_dev_download(ctx_ivf_, hid.data(), d_hid_, (size_t)B * hk * 8) == FVDB_OK &&
+             fvdb_dev_download(ctx_ivf_, hd.data(), d_hd_, (size_t)B * hk * 4) == FVDB_OK &&
+             fvdb_dev_download(ctx_ivf_, hc.data(), d_hc_, (size_t)B * 4) == FVDB_OK;
+    fvdb_ivf_profile_collect(historical_->device());
+  }
+  if (dbg) fprintf(stderr, "[hybrid] ivf downloaded\n");
   struct R {
     uint64_t id;
     float d;

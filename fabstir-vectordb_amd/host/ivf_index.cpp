@@ -155,6 +155,13 @@ int IVFIndex::search(const float* q, uint32_t B, uint32_t dim, uint32_t k, uint3
   return fvdb_ivf_search(dev_, q, B, k, n_probe, ids, dist, counts);
 }
 
+int IVFIndex::search_dev(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t n_probe, uint64_t* ids_dev,
+                         float* dist_dev, uint32_t* counts_dev) {
+  if (!trained_) return FVDB_E_NOT_TRAINED;
+  if (dim != dim_) return FVDB_E_DIM;
+  return fvdb_ivf_search_dev(dev_, q_dev, B, k, n_probe, ids_dev, dist_dev, counts_dev, nullptr);
+}
+
 // src/ivf/operations.rs:569-591
 int IVFIndex::mark_deleted(uint64_t id) {
   auto r = where_.equal_range(id);

@@ -70,6 +70,8 @@ HOST_SIGNATURES = {
     "fvh_hybrid_insert": (i32, [vp, u64, f32p, u32, dbl, dbl, i64]),
     "fvh_hybrid_bulk_insert": (i32, [vp, u64p, f32p, u64, u32, f64p, dbl]),
     "fvh_hybrid_search": (i32, [vp, f32p, u32, u32, u64, u64, u64, i32, i32, u64, u64, dbl, u64p, f32p, u32p]),
+    "fvh_hybrid_search_dev": (i32, [vp, vp, u32, u32, u64, u64, u64, i32, i32, u64, u64, dbl, u64p, f32p, u32p]),
+    "fvh_hnsw_search_dev": (i32, [vp, vp, u32, u32, u32, u32, u64p, f32p, u32p]),
     "fvh_hybrid_delete": (i32, [vp, u64, dbl]),
     "fvh_hybrid_migrate": (u64, [vp, dbl, dbl]),
     "fvh_hybrid_recent_count": (u64, [vp]),
@@ -230,6 +232,32 @@ class IVFIndex(_Base):
     def is_deleted(self, id):
         return bool(self.lib.fvh_ivf_is_deleted(self.h, int(id)))
 
+    # --- views of the device index behind this mirror (accounting, bulk helpers) ---
+    def _dev(self):
+        return C.c_void_p(self.lib.fvh_ivf_device(self.h))
+
+    def assign(self, vectors):
+        """Batched find_nearest_centroid on the GPU (src/ivf/core.rs:373-386)."""
+        v = _rows(vectors)
+        out = np.empty(v.shape[0], np.uint32)
+        self._check(self.ctx.lib.fvdb_ivf_assign(self._dev(), _ptr(v, f32p), v.shape[0], _ptr(out, u32p)))
+        return out
+
+    def list_sizes(self):
+        out = np.empty(self.n_clusters, np.uint64)
+        self._check(self.ctx.lib.fvdb_ivf_list_sizes(self._dev(), _ptr(out, u64p)))
+        return out
+
+    def stage_times(self):
+        ms = np.zeros(5, np.float32)
+        n = self.ctx.lib.fvdb_ivf_stage_times(self._dev(), _ptr(ms, f32p))
+        return int(n), dict(zip(("coarse_scan", "coarse_merge", "plan", "fine_scan", "fine_merge"), ms.tolist()))
+
+    def last_stats(self):
+        st = _capi.SearchStats()
+        self._check(self.ctx.lib.fvdb_ivf_last_stats(self._dev(), C.byref(st)))
+        return dict(rows_scanned=st.rows_scanned, work_items=st.work_items, list_rows_touched=st.list_rows_touched)
+
 
 class HNSWIndex(_Base):
     """src/hnsw/core.rs HNSWIndex (HNSWConfig::default :37-46)."""
@@ -268,6 +296,14 @@ class HNSWIndex(_Base):
 
     def search(self, queries, k, ef):
         return self._search(self.lib.fvh_hnsw_search, queries, k, ef)
+
+    def search_dev(self, q_dev, B, dim, k, ef):
+        ids = np.empty((B, max(k, 1)), np.uint64)
+        ds = np.empty((B, max(k, 1)), np.float32)
+        cnt = np.zeros(B, np.uint32)
+        self._check(self.lib.fvh_hnsw_search_dev(self.h, q_dev, B, dim, k, ef, _ptr(ids, u64p), _ptr(ds, f32p),
+                                                 _ptr(cnt, u32p)))
+        return SearchResults(ids, ds, cnt)
 
     def node_count(self):
         return int(self.lib.fvh_hnsw_node_count(self.h))
@@ -389,6 +425,17 @@ class HybridIndex(_Base):
 
     search_with_config = search
 
+    def search_dev(self, q_dev, B, k, now=0.0, hnsw_ef=50, ivf_n_probe=10, search_recent=True, search_historical=True,
+                   recent_k=0, historical_k=0, dim=None):
+        """Same search with the B x d query batch already resident in HBM (device pointer)."""
+        ids = np.empty((B, max(k, 1)), np.uint64)
+        ds = np.empty((B, max(k, 1)), np.float32)
+        cnt = np.zeros(B, np.uint32)
+        self._check(self.lib.fvh_hybrid_search_dev(self.h, q_dev, B, dim, k, hnsw_ef, ivf_n_probe, int(search_recent),
+                                                   int(search_historical), recent_k, historical_k, float(now),
+                                                   _ptr(ids, u64p), _ptr(ds, f32p), _ptr(cnt, u32p)))
+        return SearchResults(ids, ds, cnt)
+
     def delete(self, id, now=0.0):
         self._check(self.lib.fvh_hybrid_delete(self.h, int(id), float(now)))
 
@@ -403,6 +450,12 @@ class HybridIndex(_Base):
 
     def hnsw(self):
         return HNSWIndex(self.ctx_hnsw, _handle=self.lib.fvh_hybrid_hnsw(self.h))
+
+    def ivf_device_stage_times(self):
+        return self.ivf().stage_times()
+
+    def ivf_device_last_stats(self):
+        return self.ivf().last_stats()
 
     def ivf(self):
         return IVFIndex(self.ctx, n_clusters=self.n_clusters, n_probe=self.n_probe, _handle=self.lib.fvh_hybrid_ivf(self.h))

@@ -75,7 +75,9 @@ int fvdb_dev_download(fvdb_ctx* ctx, void* dst_host, const void* src_dev, size_t
 /* Stream-ordered timing of the region between the two calls (HIP events on ctx's stream). */
 int fvdb_timer_start(fvdb_ctx* ctx);
 int fvdb_timer_stop_ms(fvdb_ctx* ctx, float* out_ms);
-/* Per-stage HIP-event timing of searches on this context (adds one stream sync per search). */
+/* Per-stage HIP-event timing of searches on this context.  on = 1: each search synchronises the
+ * stream and accumulates its stage times; on = 2: events are only recorded, the caller folds them
+ * in with fvdb_ivf_profile_collect() after its own synchronisation point (no extra sync). */
 int fvdb_ctx_set_profiling(fvdb_ctx* ctx, int on);
 
 /* ---- IVF-flat ------------------------------------------------------------------------
@@ -149,6 +151,7 @@ int fvdb_ivf_last_stats(fvdb_ivf* ivf, fvdb_search_stats* out);
 /* With profiling on: ms[5] = coarse scan, coarse merge, plan, fine scan, fine merge, summed over the
  * searches since the last call; returns how many searches (sub-batches) were accumulated. */
 uint64_t fvdb_ivf_stage_times(fvdb_ivf* ivf, float* ms_out);
+int fvdb_ivf_profile_collect(fvdb_ivf* ivf);  /* profiling mode 2: fold the last search's events in */
 
 /* ---- merge ---------------------------------------------------------------------------
  * G-way merge of per-shard partial top-k by key (a4/a12 semantics: ascending, keep k).
@@ -175,6 +178,7 @@ int fvdb_scorer_create(fvdb_store* s, uint32_t max_B, uint32_t max_C, fvdb_score
 void fvdb_scorer_destroy(fvdb_scorer* sc);
 int fvdb_scorer_set_queries(fvdb_scorer* sc, const float* q, uint32_t B);      /* host rows */
 int fvdb_scorer_set_query_rows(fvdb_scorer* sc, const uint32_t* rows, uint32_t B); /* queries = stored rows */
+int fvdb_scorer_set_queries_dev(fvdb_scorer* sc, const float* q_dev, uint32_t B); /* B x d rows already in HBM */
 uint32_t* fvdb_scorer_cand_buffer(fvdb_scorer* sc);   /* B x max_C, write candidates here */
 const float* fvdb_scorer_dist_buffer(fvdb_scorer* sc); /* B x max_C, read distances here */
 int fvdb_scorer_run(fvdb_scorer* sc, uint32_t B, uint32_t C); /* scores cand_buffer[0..B x C) (stride C) */

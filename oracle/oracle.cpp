@@ -25,6 +25,7 @@
 // only matters when two distances tie exactly.
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -318,6 +319,22 @@ struct IVF {
     return ORC_OK;
   }
 
+  // Test/bench setup only: same as insert() with the cluster supplied by the caller (a cluster
+  // that tests/test_gpu_ivf_parity.py shows equal to find_nearest_centroid's) — skips the O(nlist*d)
+  // scan so a million-row baseline index can be built in seconds.
+  int insert_assigned(uint64_t id, const float* v, size_t dim, size_t c) {
+    if (!trained) return ORC_NOT_TRAINED;
+    if (dim != d) return ORC_DIM_MISMATCH;
+    if (c >= n_clusters) return ORC_INVALID;
+    if (lists[c].idset.count(id)) return ORC_DUPLICATE;
+    lists[c].idset.insert(id);
+    lists[c].ids.push_back(id);
+    lists[c].vectors.insert(lists[c].vectors.end(), v, v + d);
+    where[id] += 1;
+    total_vectors += 1;
+    return ORC_OK;
+  }
+
   // src/ivf/core.rs:626-681
   int search(const float* q, size_t dim, size_t k, size_t nprobe, uint64_t* out_ids,
              float* out_dist, uint32_t* out_count) const {
@@ -404,7 +421,7 @@ struct HNSW {
   uint64_t entry_point = 0;
   std::vector<HNode> nodes;                       // insertion order
   std::unordered_map<uint64_t, size_t> index_of;  // id -> nodes[]
-  uint64_t n_dist = 0;                            // distance evaluations (bench accounting)
+  std::atomic<uint64_t> n_dist{0};                // distance evaluations (bench accounting)
 
   HNSW(size_t m, size_t m0, size_t efc, uint64_t seed)
       : M(m), M0(m0), ef_construction(efc), rng(seed) {}
@@ -850,6 +867,14 @@ int orc_ivf_insert_batch(void* p, const uint64_t* ids, const float* v, uint64_t 
   }
   return ORC_OK;
 }
+int orc_ivf_insert_assigned_batch(void* p, const uint64_t* ids, const float* v, uint64_t n, uint64_t d,
+                                  const uint32_t* clusters) {
+  for (uint64_t i = 0; i < n; ++i) {
+    int rc = ((IVF*)p)->insert_assigned(ids[i], v + i * d, d, clusters[i]);
+    if (rc) return rc;
+  }
+  return ORC_OK;
+}
 int orc_ivf_find_cluster(void* p, const float* v, uint64_t d, uint64_t* out) {
   IVF* x = (IVF*)p;
   if (!x->trained) return ORC_NOT_TRAINED;
@@ -950,7 +975,7 @@ int64_t orc_hnsw_neighbors(void* p, uint64_t id, uint64_t layer, uint64_t* out, 
 }
 int orc_hnsw_mark_deleted(void* p, uint64_t id) { return ((HNSW*)p)->mark_deleted(id); }
 uint64_t orc_hnsw_vacuum(void* p) { return ((HNSW*)p)->vacuum(); }
-uint64_t orc_hnsw_dist_evals(void* p) { return ((HNSW*)p)->n_dist; }
+uint64_t orc_hnsw_dist_evals(void* p) { return ((HNSW*)p)->n_dist.load(); }
 // Install a graph built elsewhere (bench: bulk-built graph fed to both backends).
 // level[i], and for each node and layer a neighbour list given CSR-style.
 int orc_hnsw_restore(void* p, const uint64_t* ids, const float* vecs, uint64_t n, uint64_t d,
@@ -1009,6 +1034,30 @@ int orc_hybrid_search(void* p, const float* q, uint64_t d, uint64_t k, uint64_t 
                       double now, uint64_t* ids, float* dist, uint32_t* count) {
   return ((Hybrid*)p)->search(q, d, k, ef, nprobe, search_recent, search_historical, recent_k,
                               historical_k, now, ids, dist, count);
+}
+// B queries; the auto-migration runs once up front (as the first query's search would do), then
+// queries are searched one per thread (threads = 1: the reference's sequential behaviour).
+int orc_hybrid_batch_search(void* p, const float* q, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t nprobe,
+                            double now, uint64_t* ids, float* dist, uint32_t* counts, uint32_t threads) {
+  Hybrid* h = (Hybrid*)p;
+  if (h->initialized && h->auto_migrate) h->migrate_with_threshold(h->recent_threshold_s, now);
+  const bool am = h->auto_migrate;
+  h->auto_migrate = false;
+  if (threads < 1) threads = 1;
+  std::vector<std::thread> th;
+  std::vector<int> rcs(threads, 0);
+  for (uint32_t t = 0; t < threads; ++t)
+    th.emplace_back([&, t]() {
+      for (uint64_t i = t; i < nq; i += threads) {
+        int rc = h->search(q + i * d, d, k, ef, nprobe, 1, 1, 0, 0, now, ids + i * k, dist + i * k, counts + i);
+        if (rc) rcs[t] = rc;
+      }
+    });
+  for (auto& t : th) t.join();
+  h->auto_migrate = am;
+  for (int rc : rcs)
+    if (rc) return rc;
+  return ORC_OK;
 }
 int orc_hybrid_delete(void* p, uint64_t id, double now) { return ((Hybrid*)p)->del(id, now); }
 uint64_t orc_hybrid_migrate(void* p, double threshold_s, double now) {

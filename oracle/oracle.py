@@ -110,6 +110,7 @@ def lib():
         "orc_ivf_get_centroids": (ci, [vp, _f32p]),
         "orc_ivf_insert": (ci, [vp, u64, _f32p, u64]),
         "orc_ivf_insert_batch": (ci, [vp, _u64p, _f32p, u64, u64]),
+        "orc_ivf_insert_assigned_batch": (ci, [vp, _u64p, _f32p, u64, u64, _u32p]),
         "orc_ivf_find_cluster": (ci, [vp, _f32p, u64, _u64p]),
         "orc_ivf_assign_batch": (ci, [vp, _f32p, u64, u64, _u32p]),
         "orc_ivf_cluster_size": (u64, [vp, u64]),
@@ -140,6 +141,7 @@ def lib():
         "orc_hybrid_get_ivf_centroids": (ci, [vp, _f32p]),
         "orc_hybrid_insert": (ci, [vp, u64, _f32p, u64, dbl, dbl, i64]),
         "orc_hybrid_search": (ci, [vp, _f32p, u64, u64, u64, u64, ci, ci, u64, u64, dbl, _u64p, _f32p, _u32p]),
+        "orc_hybrid_batch_search": (ci, [vp, _f32p, u64, u64, u64, u64, u64, dbl, _u64p, _f32p, _u32p, u32]),
         "orc_hybrid_delete": (ci, [vp, u64, dbl]),
         "orc_hybrid_migrate": (u64, [vp, dbl, dbl]),
         "orc_hybrid_recent_count": (u64, [vp]),
@@ -287,6 +289,13 @@ class IVFIndex:
         ids = np.ascontiguousarray(ids, np.uint64)
         v = _f32(vectors)
         _check(lib().orc_ivf_insert_batch(self._h, _p(ids, _u64p), _p(v, _f32p), v.shape[0], v.shape[1]))
+
+    def batch_insert_assigned(self, ids, vectors, clusters):
+        """Setup helper: insert with clusters already known (see oracle.cpp insert_assigned)."""
+        ids = np.ascontiguousarray(ids, np.uint64)
+        v = _f32(vectors)
+        cl = np.ascontiguousarray(clusters, np.uint32)
+        _check(lib().orc_ivf_insert_assigned_batch(self._h, _p(ids, _u64p), _p(v, _f32p), v.shape[0], v.shape[1], _p(cl, _u32p)))
 
     def find_cluster(self, vector):
         v = _f32(vector)
@@ -461,6 +470,16 @@ class HybridIndex:
                         int(search_historical), recent_k, historical_k, float(now))
 
     search_with_config = search
+
+    def batch_search(self, queries, k, now=0.0, hnsw_ef=50, ivf_n_probe=10, threads=1):
+        q = _f32(queries)
+        nq, d = q.shape
+        ids = np.full((nq, max(k, 1)), 2**64 - 1, np.uint64)
+        ds = np.full((nq, max(k, 1)), np.inf, np.float32)
+        cnt = np.zeros(nq, np.uint32)
+        _check(lib().orc_hybrid_batch_search(self._h, _p(q, _f32p), nq, d, k, hnsw_ef, ivf_n_probe, float(now),
+                                             _p(ids, _u64p), _p(ds, _f32p), _p(cnt, _u32p), threads))
+        return ids, ds, cnt
 
     def delete(self, id, now=0.0):
         _check(lib().orc_hybrid_delete(self._h, int(id), float(now)))
