@@ -9,6 +9,8 @@ The directory name carries a hyphen, so import it through `fvdb_import.py` at th
 (`import fvdb_import; pkg = fvdb_import.load()`), which registers it as `fabstir_vectordb_amd`.
 """
 from . import _capi  # noqa: F401
+from . import engine  # noqa: F401
 from .engine import *  # noqa: F401,F403
 from .engine import Context, DeviceIVF, RowStore  # noqa: F401
 from .index import IVFIndex, HNSWIndex, HybridIndex, SearchResults, load_host  # noqa: F401,E402
+from . import sharded  # noqa: F401,E402

@@ -146,6 +146,10 @@ int fvh_hybrid_bulk_insert(void* p, const uint64_t* ids, const float* v, uint64_
                            double now) {
   return ((HybridIndex*)p)->bulk_insert(ids, v, n, d, ts, now);
 }
+int fvh_hybrid_bulk_insert_sharded(void* p, const uint64_t* ids, const float* v, uint64_t n, uint32_t d,
+                                   const double* ts, double now, uint32_t rank, uint32_t world, uint32_t* owner_out) {
+  return ((HybridIndex*)p)->bulk_insert_sharded(ids, v, n, d, ts, now, rank, world, owner_out);
+}
 int fvh_hybrid_search(void* p, const float* q, uint32_t B, uint32_t d, uint64_t k, uint64_t ef, uint64_t nprobe,
                       int search_recent, int search_historical, uint64_t recent_k, uint64_t historical_k, double now,
                       uint64_t* ids, float* dist, uint32_t* counts) {

@@ -82,6 +82,10 @@ class IVFIndex {
   int insert(uint64_t id, const float* v, uint32_t dim);                          // :431
   // batch_insert (operations.rs:107-130): sequential semantics, one GPU assignment pass.
   int batch_insert(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, uint64_t* n_ok, int* first_error);
+  // rows whose list is already known (load path / shard placement)
+  int batch_insert_assigned(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const uint32_t* clusters,
+                            uint64_t* n_ok, int* first_error);
+  int assign(const float* v, uint64_t n, uint32_t dim, uint32_t* out);
   int find_cluster(const float* v, uint32_t dim, uint32_t* out);                  // :493
   int search(const float* q, uint32_t B, uint32_t dim, uint32_t k, uint32_t n_probe, uint64_t* ids, float* dist,
              uint32_t* counts);                                                   // :626, operations.rs:132
@@ -243,6 +247,12 @@ class HybridIndex {
   IVFIndex& historical() { return *historical_; }
   // bulk loaders for scale runs: route by age like insert_with_timestamp, batched on the GPU
   int bulk_insert(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const double* ts, double now);
+  // Multi-GPU placement: the same, but of the historical rows only those whose IVF list is owned by
+  // `rank` (owner[list] == rank) are stored on this GPU; the logical list sizes are installed so the
+  // tie-break position is global.  With owner == nullptr, lists are dealt largest-first to the least
+  // loaded of `world` ranks (deterministic, identical on every rank).  The HNSW part is replicated.
+  int bulk_insert_sharded(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const double* ts, double now,
+                          uint32_t rank, uint32_t world, uint32_t* owner_out /* nlist, optional */);
 
  private:
   static double age_of(double now, double ts) { return now - ts < 0 ? 0.0 : now - ts; }

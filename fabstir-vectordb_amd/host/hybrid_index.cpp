@@ -101,6 +101,76 @@ int HybridIndex::bulk_insert(const uint64_t* ids, const float* v, uint64_t n, ui
   return FVDB_OK;
 }
 
+// Greedy "largest list to the least loaded rank" placement; ties -> lower rank.
+static void plan_list_owners(const std::vector<uint64_t>& sizes, uint32_t world, std::vector<uint32_t>& owner) {
+  const size_t nlist = sizes.size();
+  std::vector<uint32_t> order(nlist);
+  for (size_t i = 0; i < nlist; ++i) order[i] = (uint32_t)i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sizes[a] > sizes[b]; });
+  std::vector<uint64_t> load(world, 0);
+  owner.assign(nlist, 0);
+  for (uint32_t L : order) {
+    uint32_t best = 0;
+    for (uint32_t r = 1; r < world; ++r)
+      if (load[r] < load[best]) best = r;
+    owner[L] = best;
+    load[best] += sizes[L];
+  }
+}
+
+int HybridIndex::bulk_insert_sharded(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const double* ts,
+                                     double now, uint32_t rank, uint32_t world, uint32_t* owner_out) {
+  if (!initialized_) return FVDB_E_NOT_INITIALIZED;
+  if (!ts_order_.empty() || world == 0 || rank >= world) return FVDB_E_INVALID;
+  std::vector<uint64_t> rid, hid;
+  std::vector<float> rv, hv;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (timestamps_.count(ids[i])) return FVDB_E_DUPLICATE;
+    timestamps_[ids[i]] = ts[i];
+    const bool to_recent = !ivf_trained_ || age_of(now, ts[i]) < cfg_.recent_threshold_s;
+    auto& I = to_recent ? rid : hid;
+    auto& V = to_recent ? rv : hv;
+    I.push_back(ids[i]);
+    V.insert(V.end(), v + i * dim, v + (i + 1) * dim);
+  }
+  ts_order_.assign(ids, ids + n);
+  if (!rid.empty()) {  // replicated graph: every rank builds the same one
+    int rc = recent_->bulk_build(rid.data(), rv.data(), rid.size(), dim, nullptr);
+    if (rc) return rc;
+    recent_count_ = rid.size();
+    pending_migration_ = rid;
+  }
+  if (!hid.empty()) {
+    const uint32_t nlist = historical_->config().n_clusters;
+    std::vector<uint32_t> cl(hid.size());
+    int rc = historical_->assign(hv.data(), hid.size(), dim, cl.data());
+    if (rc) return rc;
+    std::vector<uint64_t> sizes(nlist, 0);
+    for (uint32_t c : cl) sizes[c]++;
+    std::vector<uint32_t> owner;
+    plan_list_owners(sizes, world, owner);
+    if (owner_out) std::memcpy(owner_out, owner.data(), nlist * sizeof(uint32_t));
+    std::vector<uint64_t> kid;
+    std::vector<float> kv;
+    std::vector<uint32_t> kc;
+    for (size_t i = 0; i < hid.size(); ++i)
+      if (owner[cl[i]] == rank) {
+        kid.push_back(hid[i]);
+        kc.push_back(cl[i]);
+        kv.insert(kv.end(), hv.begin() + i * dim, hv.begin() + (i + 1) * dim);
+      }
+    uint64_t ok = 0;
+    int err = 0;
+    rc = historical_->batch_insert_assigned(kid.data(), kv.data(), kid.size(), dim, kc.data(), &ok, &err);
+    if (rc) return rc;
+    if (err) return err;
+    rc = fvdb_ivf_set_global_list_sizes(historical_->device(), sizes.data());
+    if (rc) return rc;
+    historical_count_ = hid.size();  // logical count; this rank stores `ok` of them
+  }
+  return FVDB_OK;
+}
+
 // src/hybrid/core.rs:600-649 — copies into IVF, never removes from HNSW (:577-581)
 uint64_t HybridIndex::migrate_with_threshold(double threshold_s, double now) {
   if (pending_migration_.empty()) return 0;

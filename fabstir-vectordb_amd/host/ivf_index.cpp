@@ -147,6 +147,22 @@ int IVFIndex::batch_insert(const uint64_t* ids, const float* v, uint64_t n, uint
   return place(ids, v, n, clusters.data(), n_ok, first_error);
 }
 
+int IVFIndex::batch_insert_assigned(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim,
+                                    const uint32_t* clusters, uint64_t* n_ok, int* first_error) {
+  if (n_ok) *n_ok = 0;
+  if (first_error) *first_error = 0;
+  if (!trained_) return FVDB_E_NOT_TRAINED;
+  if (dim != dim_) return FVDB_E_DIM;
+  if (n == 0) return FVDB_OK;
+  return place(ids, v, n, clusters, n_ok, first_error);
+}
+
+int IVFIndex::assign(const float* v, uint64_t n, uint32_t dim, uint32_t* out) {
+  if (!trained_) return FVDB_E_NOT_TRAINED;
+  if (dim != dim_) return FVDB_E_DIM;
+  return fvdb_ivf_assign(dev_, v, n, out);
+}
+
 // src/ivf/core.rs:626-681 for a batch (src/ivf/operations.rs:132-145)
 int IVFIndex::search(const float* q, uint32_t B, uint32_t dim, uint32_t k, uint32_t n_probe, uint64_t* ids,
                      float* dist, uint32_t* counts) {

@@ -69,6 +69,7 @@ HOST_SIGNATURES = {
     "fvh_hybrid_set_ivf_centroids": (i32, [vp, f32p, u32]),
     "fvh_hybrid_insert": (i32, [vp, u64, f32p, u32, dbl, dbl, i64]),
     "fvh_hybrid_bulk_insert": (i32, [vp, u64p, f32p, u64, u32, f64p, dbl]),
+    "fvh_hybrid_bulk_insert_sharded": (i32, [vp, u64p, f32p, u64, u32, f64p, dbl, u32, u32, u32p]),
     "fvh_hybrid_search": (i32, [vp, f32p, u32, u32, u64, u64, u64, i32, i32, u64, u64, dbl, u64p, f32p, u32p]),
     "fvh_hybrid_search_dev": (i32, [vp, vp, u32, u32, u64, u64, u64, i32, i32, u64, u64, dbl, u64p, f32p, u32p]),
     "fvh_hnsw_search_dev": (i32, [vp, vp, u32, u32, u32, u32, u64p, f32p, u32p]),
@@ -416,6 +417,17 @@ class HybridIndex(_Base):
         ts = np.ascontiguousarray(timestamps, np.float64)
         self._check(self.lib.fvh_hybrid_bulk_insert(self.h, _ptr(ids, u64p), _ptr(v, f32p), v.shape[0], v.shape[1],
                                                     _ptr(ts, f64p), float(now)))
+
+    def bulk_insert_sharded(self, ids, vectors, timestamps, now, rank, world):
+        """Multi-GPU placement: HNSW replicated, IVF lists owned by `rank` only.  Returns owner[nlist]."""
+        v = _rows(vectors)
+        ids = np.ascontiguousarray(ids, np.uint64)
+        ts = np.ascontiguousarray(timestamps, np.float64)
+        owner = np.zeros(self.n_clusters, np.uint32)
+        self._check(self.lib.fvh_hybrid_bulk_insert_sharded(self.h, _ptr(ids, u64p), _ptr(v, f32p), v.shape[0],
+                                                            v.shape[1], _ptr(ts, f64p), float(now), rank, world,
+                                                            _ptr(owner, u32p)))
+        return owner
 
     def search(self, queries, k, now=0.0, hnsw_ef=50, ivf_n_probe=10, search_recent=True, search_historical=True,
                recent_k=0, historical_k=0):
