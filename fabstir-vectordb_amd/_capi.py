@@ -74,6 +74,8 @@ SIGNATURES = {
     "fvdb_scorer_cand_buffer": (u32p, [vp]),
     "fvdb_scorer_dist_buffer": (f32p, [vp]),
     "fvdb_scorer_run": (i32, [vp, u32, u32]),
+    "fvdb_scorer_launch": (i32, [vp, u32, u32]),
+    "fvdb_scorer_wait": (i32, [vp]),
 }
 
 _lib = None

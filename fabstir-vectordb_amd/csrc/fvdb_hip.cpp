@@ -182,13 +182,14 @@ struct fvdb_store {
 
 struct fvdb_scorer {
   fvdb_store* store = nullptr;
+  hipStream_t stream = nullptr;  // private stream: scorers of different host threads run concurrently
   uint32_t max_B = 0, max_C = 0;
   float* d_q = nullptr;        // [max_B][dpad]
   uint32_t* h_cand = nullptr;  // pinned, mapped
   float* h_dist = nullptr;     // pinned, mapped
   uint32_t* d_cand = nullptr;  // device aliases of the mapped buffers
   float* d_dist = nullptr;
-  DBuf s_rows;
+  DBuf s_rows, s_in;  // private scratch: scorers are driven from different host threads
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1192,7 +1193,8 @@ int fvdb_scorer_create(fvdb_store* s, uint32_t max_B, uint32_t max_C, fvdb_score
   sc->max_B = max_B;
   sc->max_C = max_C;
   const size_t nc = (size_t)max_B * max_C;
-  if (hipMalloc(&sc->d_q, (size_t)max_B * s->dpad * 4) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc(&sc->d_q, (size_t)max_B * s->dpad * 4) != hipSuccess ||
       hipHostMalloc((void**)&sc->h_cand, nc * 4, hipHostMallocMapped) != hipSuccess ||
       hipHostMalloc((void**)&sc->h_dist, nc * 4, hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&sc->d_cand, sc->h_cand, 0) != hipSuccess ||
@@ -1208,11 +1210,13 @@ int fvdb_scorer_create(fvdb_store* s, uint32_t max_B, uint32_t max_C, fvdb_score
 void fvdb_scorer_destroy(fvdb_scorer* sc) {
   if (!sc) return;
   (void)hipSetDevice(sc->store->ctx->device);
-  (void)hipStreamSynchronize(sc->store->ctx->stream);
+  if (sc->stream) (void)hipStreamSynchronize(sc->stream);
   if (sc->d_q) (void)hipFree(sc->d_q);
   if (sc->h_cand) (void)hipHostFree(sc->h_cand);
   if (sc->h_dist) (void)hipHostFree(sc->h_dist);
   sc->s_rows.release();
+  sc->s_in.release();
+  if (sc->stream) (void)hipStreamDestroy(sc->stream);
   delete sc;
 }
 
@@ -1225,14 +1229,14 @@ int fvdb_scorer_set_queries(fvdb_scorer* sc, const float* q, uint32_t B) {
   int rc = check_finite(ctx, q, (uint64_t)B * s->d);
   if (rc) return rc;
   if (s->d == s->dpad) {
-    HIPCHK(ctx, hipMemcpyAsync(sc->d_q, q, (size_t)B * s->d * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(sc->d_q, q, (size_t)B * s->d * 4, hipMemcpyHostToDevice, sc->stream));
   } else {
-    HIPCHK(ctx, s->s_in.ensure((size_t)B * s->d * 4));
-    HIPCHK(ctx, hipMemcpyAsync(s->s_in.p, q, (size_t)B * s->d * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv((uint64_t)B * s->dpad, 256)), dim3(256), 0, ctx->stream,
-                       s->s_in.as<float>(), s->d, s->dpad, (uint64_t)B, sc->d_q);
+    HIPCHK(ctx, sc->s_in.ensure((size_t)B * s->d * 4));
+    HIPCHK(ctx, hipMemcpyAsync(sc->s_in.p, q, (size_t)B * s->d * 4, hipMemcpyHostToDevice, sc->stream));
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv((uint64_t)B * s->dpad, 256)), dim3(256), 0, sc->stream,
+                       sc->s_in.as<float>(), s->d, s->dpad, (uint64_t)B, sc->d_q);
   }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(sc->stream));
   return FVDB_OK;
 }
 
@@ -1245,11 +1249,11 @@ int fvdb_scorer_set_query_rows(fvdb_scorer* sc, const uint32_t* rows, uint32_t B
   for (uint32_t i = 0; i < B; ++i)
     if (rows[i] >= s->rows) FAIL(ctx, FVDB_E_NOT_FOUND, "query row out of range");
   HIPCHK(ctx, sc->s_rows.ensure((size_t)B * 4));
-  HIPCHK(ctx, hipMemcpyAsync(sc->s_rows.p, rows, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv((uint64_t)B * s->dpad, 256)), dim3(256), 0, ctx->stream, s->data,
+  HIPCHK(ctx, hipMemcpyAsync(sc->s_rows.p, rows, (size_t)B * 4, hipMemcpyHostToDevice, sc->stream));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv((uint64_t)B * s->dpad, 256)), dim3(256), 0, sc->stream, s->data,
                      sc->s_rows.as<uint32_t>(), s->dpad, B, sc->d_q);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(sc->stream));
   return FVDB_OK;
 }
 
@@ -1260,9 +1264,9 @@ int fvdb_scorer_set_queries_dev(fvdb_scorer* sc, const float* q_dev, uint32_t B)
   if (B == 0) return FVDB_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (s->d == s->dpad) {
-    HIPCHK(ctx, hipMemcpyAsync(sc->d_q, q_dev, (size_t)B * s->d * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(sc->d_q, q_dev, (size_t)B * s->d * 4, hipMemcpyDeviceToDevice, sc->stream));
   } else {
-    hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv((uint64_t)B * s->dpad, 256)), dim3(256), 0, ctx->stream, q_dev, s->d,
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv((uint64_t)B * s->dpad, 256)), dim3(256), 0, sc->stream, q_dev, s->d,
                        s->dpad, (uint64_t)B, sc->d_q);
     HIPCHK(ctx, hipGetLastError());
   }
@@ -1272,16 +1276,27 @@ int fvdb_scorer_set_queries_dev(fvdb_scorer* sc, const float* q_dev, uint32_t B)
 uint32_t* fvdb_scorer_cand_buffer(fvdb_scorer* sc) { return sc->h_cand; }
 const float* fvdb_scorer_dist_buffer(fvdb_scorer* sc) { return sc->h_dist; }
 
-int fvdb_scorer_run(fvdb_scorer* sc, uint32_t B, uint32_t C) {
+int fvdb_scorer_launch(fvdb_scorer* sc, uint32_t B, uint32_t C) {
   fvdb_store* s = sc->store;
   fvdb_ctx* ctx = s->ctx;
   if (B > sc->max_B || C > sc->max_C) FAIL(ctx, FVDB_E_INVALID, "shape above scorer capacity");
   if (B == 0 || C == 0) return FVDB_OK;
-  hipLaunchKernelGGL(score_candidates_kernel, dim3(cdiv((uint64_t)B * C, 256)), dim3(256), 0, ctx->stream, s->data,
+  if (hipSetDevice(ctx->device) != hipSuccess) return FVDB_E_HIP;  // current device is per host thread
+  hipLaunchKernelGGL(score_candidates_kernel, dim3(cdiv((uint64_t)B * C, 256)), dim3(256), 0, sc->stream, s->data,
                      s->dpad, sc->d_q, sc->d_cand, B, C, sc->max_C, sc->d_dist);
-  HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (hipGetLastError() != hipSuccess) return FVDB_E_HIP;
   return FVDB_OK;
+}
+
+int fvdb_scorer_wait(fvdb_scorer* sc) {
+  if (hipStreamSynchronize(sc->stream) != hipSuccess) return FVDB_E_HIP;
+  return FVDB_OK;
+}
+
+int fvdb_scorer_run(fvdb_scorer* sc, uint32_t B, uint32_t C) {
+  int rc = fvdb_scorer_launch(sc, B, C);
+  if (rc) return rc;
+  return fvdb_scorer_wait(sc);
 }
 
 }  // extern "C"

@@ -176,6 +176,30 @@ class HNSWIndex {
   int score_pairs_from_row(uint32_t base_row, const std::vector<uint32_t>& cands, std::vector<float>& out);
   int search_impl(const float* q, bool q_on_device, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids,
                   float* dist, uint32_t* counts);
+  // Pipelined batch search: queries are split into a few lanes (one scorer = one HIP stream each) driven
+  // round-robin, so that while the GPU scores one lane's hop the host applies and prepares another's.
+  // Per query the operation sequence is still search_layer's.
+  struct Lane {
+    fvdb_scorer* sc = nullptr;
+    uint32_t cap_B = 0, cap_C = 0;
+    std::vector<Query> qs;
+    std::vector<uint32_t> prev_cnt;
+    std::vector<std::vector<Cand>> cur;
+    uint32_t lo = 0, n = 0, layer = 0, ef = 0, k = 0;
+    int stage = 0;  // 0 start, 1 entry scored, 2 hop in flight
+    int threads = 1;  // OpenMP threads for this lane's host phases
+    bool done = true;
+    int rc = 0;
+    uint64_t dists = 0, hops = 0;
+  };
+  int lane_ensure(Lane& ln, uint32_t B, uint32_t C);
+  void lane_layer_init(Lane& ln);
+  uint32_t lane_hop_prepare(Lane& ln);
+  void lane_hop_apply(Lane& ln);
+  void lane_layer_collect(Lane& ln);
+  void lane_advance(Lane& ln, const float* q, bool q_on_device, uint32_t ef_final, uint64_t* ids, float* dist,
+                    uint32_t* counts);
+  std::vector<Lane> lanes_;
 
   fvdb_ctx* ctx_;
   HNSWConfig cfg_;
@@ -195,6 +219,7 @@ class HNSWIndex {
   std::vector<float> host_vecs_;
   std::vector<Query> qs_;
   uint64_t n_dist_ = 0, n_hops_ = 0;
+  double t_prepare_us_ = 0, t_gpu_us_ = 0, t_apply_us_ = 0;
   int threads_ = 0;
 };
 

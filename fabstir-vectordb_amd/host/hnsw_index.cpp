@@ -5,6 +5,7 @@
 #include <omp.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -135,6 +136,8 @@ static inline bool set_insert(std::vector<uint32_t>& s, uint32_t v) {
 HNSWIndex::HNSWIndex(fvdb_ctx* ctx, const HNSWConfig& cfg) : ctx_(ctx), cfg_(cfg), rng_(cfg.seed) {}
 
 HNSWIndex::~HNSWIndex() {
+  for (auto& ln : lanes_)
+    if (ln.sc) fvdb_scorer_destroy(ln.sc);
   if (scorer_) fvdb_scorer_destroy(scorer_);
   if (store_) fvdb_store_destroy(store_);
 }
@@ -246,7 +249,10 @@ int HNSWIndex::search_layer_batch(uint32_t B, const std::vector<Cand>& entries, 
     s.active = true;
   }
 
+  using clk = std::chrono::steady_clock;
+  auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
   for (;;) {
+    const auto t_a = clk::now();
     uint32_t hopC = 0;
     uint64_t hop_dists = 0;
 #pragma omp parallel for schedule(static) num_threads(nt) reduction(max : hopC) reduction(+ : hop_dists) if (par)
@@ -286,9 +292,10 @@ int HNSWIndex::search_layer_batch(uint32_t B, const std::vector<Cand>& entries, 
     }
     if (hopC == 0) break;
     static const bool dbg = getenv("FVDB_DEBUG") != nullptr;
-    if (dbg && (n_hops_ % 50 == 0)) fprintf(stderr, "[hnsw] layer %u hop %llu C=%u dists=%llu\n", layer, (unsigned long long)n_hops_, hopC, (unsigned long long)hop_dists);
+    const auto t_b = clk::now();
     int rc = fvdb_scorer_run(scorer_, B, hopC);
     if (rc) return rc;
+    const auto t_c = clk::now();
     n_hops_ += 1;
     n_dist_ += hop_dists;
 #pragma omp parallel for schedule(static) num_threads(nt) if (par)
@@ -304,6 +311,11 @@ int HNSWIndex::search_layer_batch(uint32_t B, const std::vector<Cand>& entries, 
         }
       }
     }
+    const auto t_d = clk::now();
+    t_prepare_us_ += us(t_a, t_b);
+    t_gpu_us_ += us(t_b, t_c);
+    t_apply_us_ += us(t_c, t_d);
+    (void)dbg;
   }
 
 #pragma omp parallel for schedule(static) num_threads(nt) if (par)
@@ -330,6 +342,167 @@ int HNSWIndex::search_dev(const float* q_dev, uint32_t B, uint32_t dim, uint32_t
   return search_impl(q_dev, true, B, dim, k, ef, ids, dist, counts);
 }
 
+// ---- lane primitives: search_layer (:469-554) split into init / prepare-hop / apply-hop / collect ----
+int HNSWIndex::lane_ensure(Lane& ln, uint32_t B, uint32_t C) {
+  if (ln.sc && ln.cap_B >= B && ln.cap_C >= C) return FVDB_OK;
+  if (ln.sc) fvdb_scorer_destroy(ln.sc);
+  ln.sc = nullptr;
+  ln.cap_B = std::max(B, ln.cap_B);
+  ln.cap_C = std::max(C, ln.cap_C);
+  return fvdb_scorer_create(store_, ln.cap_B, ln.cap_C, &ln.sc);
+}
+
+void HNSWIndex::lane_layer_init(Lane& ln) {
+#pragma omp parallel for schedule(static) num_threads(ln.threads) if (ln.threads > 1)
+  for (uint32_t b = 0; b < ln.n; ++b) {
+    Query& s = ln.qs[b];
+    s.candidates.clear();
+    s.nearest.clear();
+    s.pending.clear();
+    s.visited.reset((size_t)ln.ef * 8 + 64);
+    const Cand e = ln.cur[b][0];
+    s.candidates.push({e.node, e.distance});
+    s.nearest.push({e.node, -e.distance});
+    s.visited.insert(e.node);
+    s.active = true;
+  }
+}
+
+uint32_t HNSWIndex::lane_hop_prepare(Lane& ln) {
+  uint32_t* cand = fvdb_scorer_cand_buffer(ln.sc);
+  const uint32_t maxC = ln.cap_C, layer = ln.layer;
+  uint32_t hopC = 0;
+  uint64_t nd = 0;
+#pragma omp parallel for schedule(static) num_threads(ln.threads) reduction(max : hopC) reduction(+ : nd) if (ln.threads > 1)
+  for (uint32_t b = 0; b < ln.n; ++b) {
+    Query& s = ln.qs[b];
+    s.pending.clear();
+    if (s.active) {
+      for (;;) {
+        if (s.candidates.empty()) {
+          s.active = false;
+          break;
+        }
+        const Cand cur = s.candidates.pop();
+        if (cur.distance > -s.nearest.peek().distance) {  // :499-501
+          s.active = false;
+          break;
+        }
+        const uint32_t node = cur.node;
+        if (registered_[node] && level_[node] >= layer) {
+          for (uint32_t nbv : nbrs_[node][layer]) {
+            if (!s.visited.insert(nbv)) continue;  // :506-507
+            if (!registered_[nbv]) continue;       // :509
+            if (deleted_[nbv]) continue;           // :511-513
+            s.pending.push_back(nbv);
+          }
+        }
+        if (!s.pending.empty()) break;
+      }
+    }
+    uint32_t* row = cand + (size_t)b * maxC;
+    const uint32_t n = (uint32_t)s.pending.size();
+    for (uint32_t i = 0; i < n; ++i) row[i] = s.pending[i];
+    for (uint32_t i = n; i < ln.prev_cnt[b]; ++i) row[i] = FVDB_NO_ROW;
+    ln.prev_cnt[b] = n;
+    hopC = std::max(hopC, n);
+    nd += n;
+  }
+  ln.dists += nd;
+  return hopC;
+}
+
+void HNSWIndex::lane_hop_apply(Lane& ln) {
+  const float* dist = fvdb_scorer_dist_buffer(ln.sc);
+  const uint32_t maxC = ln.cap_C, ef = ln.ef;
+#pragma omp parallel for schedule(static) num_threads(ln.threads) if (ln.threads > 1)
+  for (uint32_t b = 0; b < ln.n; ++b) {
+    Query& s = ln.qs[b];
+    const float* drow = dist + (size_t)b * maxC;
+    for (size_t i = 0; i < s.pending.size(); ++i) {
+      const float d = drow[i];
+      if (d < -s.nearest.peek().distance || s.nearest.len() < ef) {  // :517-519
+        s.candidates.push({s.pending[i], d});
+        s.nearest.push({s.pending[i], -d});
+        if (s.nearest.len() > ef) s.nearest.pop();
+      }
+    }
+  }
+}
+
+void HNSWIndex::lane_layer_collect(Lane& ln) {
+#pragma omp parallel for schedule(static) num_threads(ln.threads) if (ln.threads > 1)
+  for (uint32_t b = 0; b < ln.n; ++b) {
+    Query& s = ln.qs[b];
+    if (s.nearest.empty()) continue;  // search_layer returned nothing: keep the previous nearest (:445-447)
+    auto& r = ln.cur[b];
+    r.clear();
+    r.reserve(s.nearest.len());
+    for (const Cand& c : s.nearest.data) r.push_back({c.node, -c.distance});  // :541-547
+    std::stable_sort(r.begin(), r.end(), [](const Cand& a, const Cand& c) { return a.distance < c.distance; });
+  }
+}
+
+// One step of a lane's state machine: consume the GPU results that just arrived, do host work until
+// the next GPU launch is issued (or the lane's queries are finished).
+void HNSWIndex::lane_advance(Lane& ln, const float* q, bool q_on_device, uint32_t ef_final, uint64_t* ids,
+                             float* dist, uint32_t* counts) {
+  if (ln.done) return;
+  if (ln.stage == 0) {  // load this lane's queries, score the entry point (:432-435)
+    ln.rc = q_on_device ? fvdb_scorer_set_queries_dev(ln.sc, q + (size_t)ln.lo * dim_, ln.n)
+                        : fvdb_scorer_set_queries(ln.sc, q + (size_t)ln.lo * dim_, ln.n);
+    if (ln.rc) { ln.done = true; return; }
+    uint32_t* cand = fvdb_scorer_cand_buffer(ln.sc);
+    for (uint32_t b = 0; b < ln.n; ++b) {
+      cand[(size_t)b * ln.cap_C] = entry_;
+      ln.prev_cnt[b] = std::max<uint32_t>(ln.prev_cnt[b], 1);
+    }
+    ln.rc = fvdb_scorer_launch(ln.sc, ln.n, 1);
+    if (ln.rc) { ln.done = true; return; }
+    ln.dists += ln.n;
+    ln.hops += 1;
+    ln.stage = 1;
+    return;
+  }
+  if (ln.stage == 1) {
+    const float* dbuf = fvdb_scorer_dist_buffer(ln.sc);
+    for (uint32_t b = 0; b < ln.n; ++b) ln.cur[b].assign(1, Cand{entry_, dbuf[(size_t)b * ln.cap_C]});
+    ln.layer = level_[entry_];
+    ln.ef = ln.layer == 0 ? ef_final : 1;
+    lane_layer_init(ln);
+    ln.stage = 2;
+  } else {
+    lane_hop_apply(ln);
+  }
+  for (;;) {
+    const uint32_t C = lane_hop_prepare(ln);
+    if (C > 0) {
+      ln.rc = fvdb_scorer_launch(ln.sc, ln.n, C);
+      if (ln.rc) ln.done = true;
+      ln.hops += 1;
+      return;
+    }
+    lane_layer_collect(ln);
+    if (ln.layer == 0) break;
+    ln.layer -= 1;
+    ln.ef = ln.layer == 0 ? ef_final : 1;
+    lane_layer_init(ln);
+  }
+  for (uint32_t b = 0; b < ln.n; ++b) {  // :451-466 filter deleted, take k
+    uint32_t w = 0;
+    const size_t o = (size_t)(ln.lo + b) * ln.k;
+    for (const Cand& c : ln.cur[b]) {
+      if (!registered_[c.node] || deleted_[c.node]) continue;
+      if (w >= ln.k) break;
+      ids[o + w] = ids_[c.node];
+      dist[o + w] = c.distance;
+      ++w;
+    }
+    counts[ln.lo + b] = w;
+  }
+  ln.done = true;
+}
+
 int HNSWIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef,
                            uint64_t* ids, float* dist, uint32_t* counts) {
   for (uint32_t b = 0; b < B; ++b) counts[b] = 0;
@@ -340,47 +513,59 @@ int HNSWIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint32_
   if (!has_entry_) return FVDB_OK;  // empty index -> empty results (:404-407)
   if (has_dim_ && dim != dim_) return FVDB_E_DIM;
   if (B == 0) return FVDB_OK;
-  const uint32_t step = 4096;
+  static const int auto_threads = usable_cpus();
+  const int nt = std::max(1, threads_ > 0 ? threads_ : auto_threads);
   const uint32_t maxdeg = std::max(cfg_.max_connections, cfg_.max_connections_layer_0) + 1;
+  // Lanes (one HIP stream each) can be driven round-robin by the calling thread so that one lane's hop
+  // is on the GPU while another's host phase runs.  Measured on MI355X (profiles/r01_hnsw_lanes.log):
+  // launch + stream sync cost more than the overlap wins — 1 lane 15.5 ms/step, 2 lanes 18.1, 3 lanes
+  // 27.2 (1024 queries, 300K nodes) — so the default is ONE lane = one launch per hop for the whole batch.
+  static const uint32_t max_lanes = getenv("FVDB_HNSW_LANES") ? std::max(1, atoi(getenv("FVDB_HNSW_LANES"))) : 1;
+  const uint32_t step = 16384;
   for (uint32_t o = 0; o < B; o += step) {
     const uint32_t b = std::min(step, B - o);
-    int rc = ensure_scorer(b, maxdeg);
-    if (rc) return rc;
-    rc = q_on_device ? fvdb_scorer_set_queries_dev(scorer_, q + (size_t)o * dim, b)
-                     : fvdb_scorer_set_queries(scorer_, q + (size_t)o * dim, b);
-    if (rc) return rc;
-    // nearest = [(entry, dist(q, entry))]  (:432-435): one hop with a single candidate
-    uint32_t* cand = fvdb_scorer_cand_buffer(scorer_);
-    for (uint32_t i = 0; i < b; ++i) cand[(size_t)i * scorer_C_] = entry_;
-    rc = fvdb_scorer_run(scorer_, b, 1);
-    if (rc) return rc;
-    n_dist_ += b;
-    n_hops_ += 1;
-    const float* dbuf = fvdb_scorer_dist_buffer(scorer_);
-    std::vector<Cand> nearest0(b);
-    for (uint32_t i = 0; i < b; ++i) nearest0[i] = {entry_, dbuf[(size_t)i * scorer_C_]};
-    std::vector<uint8_t> has(b, 1);
-    std::vector<std::vector<Cand>> res, cur(b);
-    for (uint32_t i = 0; i < b; ++i) cur[i] = {nearest0[i]};
-    const uint32_t top = level_[entry_];
-    for (uint32_t lc = top + 1; lc-- > 0;) {
-      std::vector<Cand> entries(b);
-      for (uint32_t i = 0; i < b; ++i) entries[i] = cur[i][0];
-      rc = search_layer_batch(b, entries, has, lc == 0 ? ef : 1, lc, res);
+    uint32_t nl = std::min<uint32_t>(max_lanes, std::max<uint32_t>(1, b / 64));
+    const uint32_t per = (b + nl - 1) / nl;
+    nl = (b + per - 1) / per;
+    if (lanes_.size() < nl) lanes_.resize(nl);
+    for (uint32_t l = 0; l < nl; ++l) {
+      Lane& ln = lanes_[l];
+      int rc = lane_ensure(ln, per, maxdeg);
       if (rc) return rc;
-      for (uint32_t i = 0; i < b; ++i)
-        if (!res[i].empty()) cur[i].swap(res[i]);
+      ln.lo = o + l * per;
+      ln.n = std::min(per, o + b - ln.lo);
+      ln.k = k;
+      ln.stage = 0;
+      ln.done = false;
+      ln.rc = 0;
+      ln.dists = ln.hops = 0;
+      ln.threads = ln.n >= 32 ? nt : 1;
+      if (ln.qs.size() < ln.n) ln.qs.resize(ln.n);
+      if (ln.cur.size() < ln.n) ln.cur.resize(ln.n);
+      ln.prev_cnt.assign(ln.cap_B, ln.cap_C);  // rows start dirty: cleared on first use
     }
-    for (uint32_t i = 0; i < b; ++i) {  // :451-466 filter deleted, take k
-      uint32_t w = 0;
-      for (const Cand& c : cur[i]) {
-        if (!registered_[c.node] || deleted_[c.node]) continue;
-        if (w >= k) break;
-        ids[(size_t)(o + i) * k + w] = ids_[c.node];
-        dist[(size_t)(o + i) * k + w] = c.distance;
-        ++w;
+    uint32_t remaining = 0;
+    for (uint32_t l = 0; l < nl; ++l) {
+      lane_advance(lanes_[l], q, q_on_device, ef, ids, dist, counts);
+      if (!lanes_[l].done) ++remaining;
+    }
+    while (remaining) {
+      for (uint32_t l = 0; l < nl; ++l) {
+        Lane& ln = lanes_[l];
+        if (ln.done) continue;
+        ln.rc = fvdb_scorer_wait(ln.sc);
+        if (ln.rc) {
+          ln.done = true;
+        } else {
+          lane_advance(ln, q, q_on_device, ef, ids, dist, counts);
+        }
+        if (ln.done) --remaining;
       }
-      counts[o + i] = w;
+    }
+    for (uint32_t l = 0; l < nl; ++l) {
+      n_dist_ += lanes_[l].dists;
+      n_hops_ += lanes_[l].hops;
+      if (lanes_[l].rc) return lanes_[l].rc;
     }
   }
   return FVDB_OK;

@@ -181,7 +181,11 @@ int fvdb_scorer_set_query_rows(fvdb_scorer* sc, const uint32_t* rows, uint32_t B
 int fvdb_scorer_set_queries_dev(fvdb_scorer* sc, const float* q_dev, uint32_t B); /* B x d rows already in HBM */
 uint32_t* fvdb_scorer_cand_buffer(fvdb_scorer* sc);   /* B x max_C, write candidates here */
 const float* fvdb_scorer_dist_buffer(fvdb_scorer* sc); /* B x max_C, read distances here */
-int fvdb_scorer_run(fvdb_scorer* sc, uint32_t B, uint32_t C); /* scores cand_buffer[0..B x C) (stride C) */
+int fvdb_scorer_run(fvdb_scorer* sc, uint32_t B, uint32_t C); /* scores cand_buffer rows 0..B, columns 0..C; waits */
+/* Each scorer owns a HIP stream: several scorers (one per host thread / query group) keep several
+ * hops in flight.  launch enqueues the scoring of rows 0..B x columns 0..C, wait blocks until it is done. */
+int fvdb_scorer_launch(fvdb_scorer* sc, uint32_t B, uint32_t C);
+int fvdb_scorer_wait(fvdb_scorer* sc);
 
 #ifdef __cplusplus
 }
