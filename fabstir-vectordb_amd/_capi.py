@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfvdb_hip.so")
+LIB_PATH = os.environ.get("FVDB_HIP_LIB") or os.path.join(_HERE, "lib", "libfvdb_hip.so")  # env: A/B builds
 
 vp, u64, u32, i32, f32, sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_float, C.c_size_t
 f32p, u64p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)

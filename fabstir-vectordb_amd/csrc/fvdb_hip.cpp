@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -210,25 +211,35 @@ struct ScanLaunch {
   const float* queries;
   uint32_t dpad, segb, k, nprobe, maxsegs;
   uint2* part;
+  uint32_t max_items = 0;  // host-side upper bound on work items (0 = unknown): sizes the persistent grid
 };
 
 inline int kr_for(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : 4); }
 inline uint32_t q_for(uint32_t k) { return k <= 64 ? 16u : (k <= 128 ? 8u : 4u); }
 
-template <int Q, int KR>
+template <int Q, int KR, int ROLE>
 void launch_scan_t(fvdb_ctx* ctx, const ScanLaunch& s) {
-  const uint32_t grid = (uint32_t)ctx->num_cus * 8u;
-  hipLaunchKernelGGL((scan_topk_kernel<Q, KR>), dim3(grid), dim3(256), 0, ctx->stream, s.pool.data, s.pool.valid,
+  static const uint32_t wgs_per_cu = getenv("FVDB_SCAN_WGS_PER_CU") ? (uint32_t)atoi(getenv("FVDB_SCAN_WGS_PER_CU")) : 8u;
+  uint32_t grid = (uint32_t)ctx->num_cus * wgs_per_cu;  // more than fit: surplus workgroups find the queue empty
+  if (s.max_items) grid = std::min(grid, std::max<uint32_t>(1u, (s.max_items + 3) / 4));  // 4 waves per workgroup
+  hipLaunchKernelGGL((scan_topk_kernel<Q, KR, ROLE>), dim3(grid), dim3(256), 0, ctx->stream, s.pool.data, s.pool.valid,
                      s.pool.d4, s.list_off, s.list_blocks, s.nlist, s.entry_off, s.item_off, (const u32x2*)s.entries,
                      s.n_items, s.head, s.queries, s.dpad, s.segb, s.k, s.nprobe, s.maxsegs, (u32x2*)s.part);
 }
 
-void launch_scan(fvdb_ctx* ctx, const ScanLaunch& s) {
+template <int ROLE>
+void launch_scan_r(fvdb_ctx* ctx, const ScanLaunch& s) {
   switch (kr_for(s.k)) {
-    case 1: launch_scan_t<16, 1>(ctx, s); break;
-    case 2: launch_scan_t<8, 2>(ctx, s); break;
-    default: launch_scan_t<4, 4>(ctx, s); break;
+    case 1: launch_scan_t<16, 1, ROLE>(ctx, s); break;
+    case 2: launch_scan_t<8, 2, ROLE>(ctx, s); break;
+    default: launch_scan_t<4, 4, ROLE>(ctx, s); break;
   }
+}
+enum { ROLE_COARSE = 0, ROLE_LIST = 1, ROLE_ALL = 2 };
+void launch_scan(fvdb_ctx* ctx, const ScanLaunch& s, int role) {
+  if (role == ROLE_COARSE) launch_scan_r<ROLE_COARSE>(ctx, s);
+  else if (role == ROLE_LIST) launch_scan_r<ROLE_LIST>(ctx, s);
+  else launch_scan_r<ROLE_ALL>(ctx, s);
 }
 
 void launch_merge(fvdb_ctx* ctx, const MergeArgs& m) {
@@ -306,9 +317,10 @@ int run_coarse(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t kc, uint32
                      scal + 0, scal + 1);
   ScanLaunch s{ivf->cpool.view(), ivf->c_off.as<uint32_t>(), ivf->c_blocks.as<uint32_t>(), 1,
                ivf->s_ceoff.as<uint32_t>(), ivf->s_cioff.as<uint32_t>(), ivf->s_entries.as<uint2>(), scal + 0,
-               scal + 1, qpad, ivf->dpad, segb, kc, 1, maxsegs, ivf->s_cpart.as<uint2>()};
+               scal + 1, qpad, ivf->dpad, segb, kc, 1, maxsegs, ivf->s_cpart.as<uint2>(),
+               cdiv(cblocks, segb) * cdiv(B, Q)};
   if (ctx->profiling) (void)hipEventRecord(ivf->sev[0], ctx->stream);
-  launch_scan(ctx, s);
+  launch_scan(ctx, s, ROLE_COARSE);
   if (ctx->profiling) (void)hipEventRecord(ivf->sev[1], ctx->stream);
   MergeArgs m{};
   m.pool = ivf->cpool.view();
@@ -330,6 +342,8 @@ int run_coarse(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t kc, uint32
 }
 
 uint32_t pick_segb(fvdb_ivf* ivf, uint32_t B, uint32_t nprobe) {
+  static const int forced = getenv("FVDB_SEGB") ? atoi(getenv("FVDB_SEGB")) : 0;  // tuning aid
+  if (forced > 0) return (uint32_t)forced;
   // enough (segment, group) items to fill 256 CUs x 32 waves, without shredding long lists
   const uint64_t pairs = (uint64_t)B * nprobe;
   if (ivf->max_list_blocks >= 4096) return 16;
@@ -340,7 +354,7 @@ uint32_t pick_segb(fvdb_ivf* ivf, uint32_t B, uint32_t nprobe) {
 
 // Fine stage for B queries whose probes[B][np] are already in HBM.
 int run_fine(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t np, const uint32_t* probes,
-             uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys) {
+             uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys, int role) {
   fvdb_ctx* ctx = ivf->ctx;
   const uint32_t nlist = ivf->nlist;
   const uint32_t segb = pick_segb(ivf, B, np), Q = q_for(k);
@@ -369,7 +383,7 @@ int run_fine(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t 
   ScanLaunch s{ivf->pool.view(), ivf->t_off.as<uint32_t>(), ivf->t_blocks.as<uint32_t>(), nlist,
                ivf->s_eoff.as<uint32_t>(), ivf->s_ioff.as<uint32_t>(), ivf->s_entries.as<uint2>(), scal + 2,
                scal + 3, qpad, ivf->dpad, segb, k, np, maxsegs, ivf->s_part.as<uint2>()};
-  launch_scan(ctx, s);
+  launch_scan(ctx, s, role);
   if (ctx->profiling) (void)hipEventRecord(ivf->sev[4], ctx->stream);
   MergeArgs m{};
   m.pool = ivf->pool.view();
@@ -802,7 +816,7 @@ static int search_common(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t
     }
     rc = run_fine(ivf, qpad, b, k, np, ivf->s_probes.as<uint32_t>(), out_ids ? out_ids + (size_t)o * k : nullptr,
                   out_dist ? out_dist + (size_t)o * k : nullptr, out_counts ? out_counts + o : nullptr,
-                  out_keys ? out_keys + (size_t)o * k : nullptr);
+                  out_keys ? out_keys + (size_t)o * k : nullptr, all ? ROLE_ALL : ROLE_LIST);
     if (rc) return rc;
     rc = finish_profile(ivf, !all, true);
     if (rc) return rc;

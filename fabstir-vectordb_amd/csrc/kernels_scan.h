@@ -30,6 +30,8 @@ namespace fvdb {
 #define FVDB_CONST_AS
 #endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16_n __attribute__((ext_vector_type(16)));
+typedef f32x16_n f32x16;  // loaded with cload16 (query rows are only 16-byte aligned in general)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // Uniform (wave-invariant) read-only loads through the constant address space => s_load_*.
@@ -37,6 +39,12 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <typename T>
 __device__ __forceinline__ T cload(const T* p) {
   return *(const FVDB_CONST_AS T*)(uintptr_t)p;
+}
+
+// 16 consecutive query dims (64 B, 16-byte aligned) through the scalar path
+__device__ __forceinline__ f32x16_n cload16(const float* p) {
+  typedef f32x16_n __attribute__((aligned(16))) f32x16_a;
+  return *(const FVDB_CONST_AS f32x16_a*)(uintptr_t)p;
 }
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -97,6 +105,24 @@ struct WaveTopK {
   }
 };
 
+// Bitonic sort of one 64-bit key per lane, ascending by lane.  Used for the first block of a work
+// item: sorting 64 candidates (21 compare-exchange steps) replaces up to 64 one-by-one insertions
+// into an empty list.
+__device__ __forceinline__ void wave_sort64(uint32_t& hi, uint32_t& lo, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t phi = __shfl_xor(hi, j), plo = __shfl_xor(lo, j);
+      const bool up = (lane & k) == 0;     // this k-block sorts ascending
+      const bool lower = (lane & j) == 0;  // lower lane of the pair
+      const bool take = (lower == up) ? key_lt(phi, plo, hi, lo) : key_lt(hi, lo, phi, plo);
+      hi = take ? phi : hi;
+      lo = take ? plo : lo;
+    }
+  }
+}
+
 // Offer one candidate per lane (chi == kInf32 => none) to the list; th/tl is the running k-th key.
 template <int KR>
 __device__ __forceinline__ void offer(WaveTopK<KR>& tk, uint32_t k, uint32_t chi, uint32_t clo, uint32_t& th,
@@ -113,10 +139,167 @@ __device__ __forceinline__ void offer(WaveTopK<KR>& tk, uint32_t k, uint32_t chi
   }
 }
 
+// One work item: rows of blocks [b0, b1) of a list against the ne (<= QQ) queries of a group.
+// QQ in {16, 8, 4}: short groups run the narrower instantiation instead of padding to 16.
+template <int QQ, int KR>
+__device__ __forceinline__ void scan_item(const float4* __restrict__ pool_data, const uint64_t* __restrict__ pool_valid,
+                                          const uint32_t d4, const uint32_t* __restrict__ list_blocks,
+                                          const u32x2* __restrict__ entries, const float* __restrict__ queries,
+                                          const uint32_t dpad, const uint32_t k, const uint32_t nprobe,
+                                          const uint32_t maxsegs, u32x2* __restrict__ part, const uint32_t b_begin,
+                                          const uint32_t b0, const uint32_t b1, const uint32_t e0, const uint32_t ne,
+                                          const uint32_t seg, const int lane) {
+  uint32_t qoff[QQ];
+#pragma unroll
+  for (int j = 0; j < QQ; ++j) {
+    const u32x2 e = cload(entries + e0 + ((uint32_t)j < ne ? j : 0));
+    qoff[j] = e.x * dpad;
+  }
+
+  WaveTopK<KR> tk[QQ];
+#pragma unroll
+  for (int j = 0; j < QQ; ++j) tk[j].init();
+
+  for (uint32_t b = b0; b < b1; ++b) {
+    const uint32_t blk = cload(list_blocks + b_begin + b);
+    const float4* xp = pool_data + (size_t)blk * d4 * 64 + lane;
+    float acc[QQ];
+#pragma unroll
+    for (int j = 0; j < QQ; ++j) acc[j] = 0.0f;
+#ifndef FVDB_SCAN_VARIANT
+#define FVDB_SCAN_VARIANT 2
+#endif
+#if FVDB_SCAN_VARIANT == 2
+    uint32_t c = 0;
+    // 16 dims per step: one s_load_dwordx16 per query feeds 48 VALU ops, so the scalar-side address
+    // arithmetic is 1/4 of a chunk-at-a-time loop's
+    for (; c + 4 <= d4; c += 4) {
+      const float4 x0 = xp[(size_t)(c + 0) * 64];
+      const float4 x1 = xp[(size_t)(c + 1) * 64];
+      const float4 x2 = xp[(size_t)(c + 2) * 64];
+      const float4 x3 = xp[(size_t)(c + 3) * 64];
+      // query j+1's 16 dims are requested before query j's are consumed (scalar loads return out of
+      // order, so the only usable wait is lgkmcnt(0): it lands after a 48-op compute block)
+      f32x16 qn = cload16(queries + qoff[0] + 4 * c);
+#pragma unroll
+      for (int j = 0; j < QQ; ++j) {
+        const f32x16 qv = qn;
+        if (j + 1 < QQ) qn = cload16(queries + qoff[j + 1] + 4 * c);
+        __builtin_amdgcn_sched_barrier(0);  // keep the request ahead of the 48 ops it overlaps with
+        float t, a = acc[j];
+        t = x0.x - qv[0]; a = a + t * t;
+        t = x0.y - qv[1]; a = a + t * t;
+        t = x0.z - qv[2]; a = a + t * t;
+        t = x0.w - qv[3]; a = a + t * t;
+        t = x1.x - qv[4]; a = a + t * t;
+        t = x1.y - qv[5]; a = a + t * t;
+        t = x1.z - qv[6]; a = a + t * t;
+        t = x1.w - qv[7]; a = a + t * t;
+        t = x2.x - qv[8]; a = a + t * t;
+        t = x2.y - qv[9]; a = a + t * t;
+        t = x2.z - qv[10]; a = a + t * t;
+        t = x2.w - qv[11]; a = a + t * t;
+        t = x3.x - qv[12]; a = a + t * t;
+        t = x3.y - qv[13]; a = a + t * t;
+        t = x3.z - qv[14]; a = a + t * t;
+        t = x3.w - qv[15]; a = a + t * t;
+        acc[j] = a;
+      }
+    }
+#elif FVDB_SCAN_VARIANT == 1
+    uint32_t c = 0;
+    // 16 dims per step: one s_load_dwordx16 per query feeds 48 VALU ops, so the scalar-side address
+    // arithmetic is 1/4 of a chunk-at-a-time loop's
+    for (; c + 4 <= d4; c += 4) {
+      const float4 x0 = xp[(size_t)(c + 0) * 64];
+      const float4 x1 = xp[(size_t)(c + 1) * 64];
+      const float4 x2 = xp[(size_t)(c + 2) * 64];
+      const float4 x3 = xp[(size_t)(c + 3) * 64];
+      // query j+1's 16 dims are requested before query j's are consumed (scalar loads return out of
+      // order, so the only usable wait is lgkmcnt(0): it lands after a 48-op compute block)
+#pragma unroll
+      for (int j = 0; j < QQ; ++j) {
+        const f32x16 qv = cload16(queries + qoff[j] + 4 * c);
+        float t, a = acc[j];
+        t = x0.x - qv[0]; a = a + t * t;
+        t = x0.y - qv[1]; a = a + t * t;
+        t = x0.z - qv[2]; a = a + t * t;
+        t = x0.w - qv[3]; a = a + t * t;
+        t = x1.x - qv[4]; a = a + t * t;
+        t = x1.y - qv[5]; a = a + t * t;
+        t = x1.z - qv[6]; a = a + t * t;
+        t = x1.w - qv[7]; a = a + t * t;
+        t = x2.x - qv[8]; a = a + t * t;
+        t = x2.y - qv[9]; a = a + t * t;
+        t = x2.z - qv[10]; a = a + t * t;
+        t = x2.w - qv[11]; a = a + t * t;
+        t = x3.x - qv[12]; a = a + t * t;
+        t = x3.y - qv[13]; a = a + t * t;
+        t = x3.z - qv[14]; a = a + t * t;
+        t = x3.w - qv[15]; a = a + t * t;
+        acc[j] = a;
+      }
+    }
+#else
+    uint32_t c = 0;
+#endif
+    for (; c < d4; ++c) {  // d4 % 4 leftover chunks
+      const float4 x = xp[(size_t)c * 64];
+#pragma unroll
+      for (int j = 0; j < QQ; ++j) {
+        const f32x4 qv = cload((const f32x4*)(queries + qoff[j] + 4 * c));
+        float t;
+        t = x.x - qv.x; acc[j] = acc[j] + t * t;
+        t = x.y - qv.y; acc[j] = acc[j] + t * t;
+        t = x.z - qv.z; acc[j] = acc[j] + t * t;
+        t = x.w - qv.w; acc[j] = acc[j] + t * t;
+      }
+    }
+    const uint64_t vmask = cload(pool_valid + blk);
+    const bool live = (vmask >> lane) & 1ull;
+    const uint32_t pos = b * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < QQ; ++j) {
+      const float dist = sqrtf(acc[j]);
+      const uint32_t chi = live ? __float_as_uint(dist) : kInf32;
+      if (b == b0) {  // empty list: the sorted block IS the list (registers 1.. stay +inf)
+        uint32_t shi = chi, slo = live ? pos : kInf32;
+        wave_sort64(shi, slo, lane);
+        tk[j].hi[0] = shi;
+        tk[j].lo[0] = slo;
+      } else {
+        uint32_t th, tl;
+        tk[j].kth(k, th, tl);
+        offer<KR>(tk[j], k, chi, pos, th, tl, lane);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < QQ; ++j) {
+    if ((uint32_t)j < ne) {
+      const u32x2 e = cload(entries + e0 + j);
+      const uint32_t slot = ((e.x * nprobe + e.y) * maxsegs + seg) * k;
+#pragma unroll
+      for (int r = 0; r < KR; ++r) {
+        const uint32_t el = r * 64 + lane;
+        if (el < k) {
+          u32x2 v;
+          v.x = tk[j].hi[r];
+          v.y = tk[j].lo[r];
+          part[slot + el] = v;
+        }
+      }
+    }
+  }
+}
+
 // -----------------------------------------------------------------------------------------
 // scan_topk: persistent waves pull (list segment, query group) items from a device work queue.
 // -----------------------------------------------------------------------------------------
-template <int Q, int KR>
+// ROLE only names the instantiation (0 = coarse ranking over the centroid table, 1 = IVF list scan,
+// 2 = exhaustive scan) so that rocprof statistics separate the three uses of the same code.
+template <int Q, int KR, int ROLE>
 __global__ __launch_bounds__(256) void scan_topk_kernel(
     const float4* __restrict__ pool_data, const uint64_t* __restrict__ pool_valid, const uint32_t d4,
     const uint32_t* __restrict__ list_off, const uint32_t* __restrict__ list_blocks, const uint32_t nlist,
@@ -151,70 +334,15 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(
     const uint32_t e0 = e_begin + g * Q;
     const uint32_t ne = min((uint32_t)Q, cnt - g * Q);
 
-    uint32_t qoff[Q];
-#pragma unroll
-    for (int j = 0; j < Q; ++j) {
-      const u32x2 e = cload(entries + e0 + ((uint32_t)j < ne ? j : 0));
-      qoff[j] = e.x * dpad;
-    }
-
-    WaveTopK<KR> tk[Q];
-#pragma unroll
-    for (int j = 0; j < Q; ++j) tk[j].init();
-
-    for (uint32_t b = b0; b < b1; ++b) {
-      const uint32_t blk = cload(list_blocks + b_begin + b);
-      const float4* xp = pool_data + (size_t)blk * d4 * 64 + lane;
-      float acc[Q];
-#pragma unroll
-      for (int j = 0; j < Q; ++j) acc[j] = 0.0f;
-      float4 x = xp[0];
-      for (uint32_t c = 0; c < d4; ++c) {
-        // next chunk's row data is in flight while this chunk is folded into Q running sums
-        const float4 xn = xp[(size_t)(c + 1 < d4 ? c + 1 : c) * 64];
-        f32x4 qv[Q];
-#pragma unroll
-        for (int j = 0; j < Q; ++j) qv[j] = cload((const f32x4*)(queries + qoff[j] + 4 * c));
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-          float t;
-          t = x.x - qv[j].x; acc[j] = acc[j] + t * t;
-          t = x.y - qv[j].y; acc[j] = acc[j] + t * t;
-          t = x.z - qv[j].z; acc[j] = acc[j] + t * t;
-          t = x.w - qv[j].w; acc[j] = acc[j] + t * t;
-        }
-        x = xn;
-      }
-      const uint64_t vmask = cload(pool_valid + blk);
-      const bool live = (vmask >> lane) & 1ull;
-      const uint32_t pos = b * 64 + lane;
-#pragma unroll
-      for (int j = 0; j < Q; ++j) {
-        const float dist = sqrtf(acc[j]);
-        const uint32_t chi = live ? __float_as_uint(dist) : kInf32;
-        uint32_t th, tl;
-        tk[j].kth(k, th, tl);
-        offer<KR>(tk[j], k, chi, pos, th, tl, lane);
-      }
-    }
-
-#pragma unroll
-    for (int j = 0; j < Q; ++j) {
-      if ((uint32_t)j < ne) {
-        const u32x2 e = cload(entries + e0 + j);
-        const uint32_t slot = ((e.x * nprobe + e.y) * maxsegs + seg) * k;
-#pragma unroll
-        for (int r = 0; r < KR; ++r) {
-          const uint32_t el = r * 64 + lane;
-          if (el < k) {
-            u32x2 v;
-            v.x = tk[j].hi[r];
-            v.y = tk[j].lo[r];
-            part[slot + el] = v;
-          }
-        }
-      }
-    }
+    if (ne <= 4)
+      scan_item<4, KR>(pool_data, pool_valid, d4, list_blocks, entries, queries, dpad, k, nprobe, maxsegs, part, b_begin,
+                       b0, b1, e0, ne, seg, lane);
+    else if (ne <= 8)
+      scan_item<8, KR>(pool_data, pool_valid, d4, list_blocks, entries, queries, dpad, k, nprobe, maxsegs, part, b_begin,
+                       b0, b1, e0, ne, seg, lane);
+    else
+      scan_item<(Q > 8 ? Q : 8), KR>(pool_data, pool_valid, d4, list_blocks, entries, queries, dpad, k, nprobe, maxsegs,
+                                     part, b_begin, b0, b1, e0, ne, seg, lane);
   }
 }
 
