@@ -74,6 +74,11 @@ SIGNATURES = {
     "fvdb_scorer_cand_buffer": (u32p, [vp]),
     "fvdb_scorer_dist_buffer": (f32p, [vp]),
     "fvdb_scorer_run": (i32, [vp, u32, u32]),
+    "fvdb_graph_create": (i32, [vp, C.POINTER(vp)]),
+    "fvdb_graph_destroy": (None, [vp]),
+    "fvdb_graph_upload": (i32, [vp, u32, u32p, C.POINTER(C.c_uint8), u32p, u32p, u32]),
+    "fvdb_graph_set_deleted": (i32, [vp, u32, i32]),
+    "fvdb_graph_search_dev": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp]),
     "fvdb_scorer_launch": (i32, [vp, u32, u32]),
     "fvdb_scorer_wait": (i32, [vp]),
 }

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "common.h"
+#include "kernels_graph.h"
 #include "kernels_misc.h"
 #include "kernels_scan.h"
 
@@ -179,6 +180,15 @@ struct fvdb_store {
   uint64_t rows = 0, cap = 0;
   float* data = nullptr;  // [cap][dpad]
   DBuf s_q, s_cand, s_out, s_in;
+};
+
+struct fvdb_graph {
+  fvdb_store* store = nullptr;
+  uint32_t n = 0, entry = 0, top_level = 0, n_slots = 0;
+  DBuf d_level, d_deleted, d_slot_of, d_slot_start, d_adj;
+  DBuf s_q, s_visited, s_touched;
+  uint32_t vis_B = 0, vis_words = 0, vis_tcap = 0;
+  bool uploaded = false;
 };
 
 struct fvdb_scorer {
@@ -1311,6 +1321,113 @@ int fvdb_scorer_run(fvdb_scorer* sc, uint32_t B, uint32_t C) {
   int rc = fvdb_scorer_launch(sc, B, C);
   if (rc) return rc;
   return fvdb_scorer_wait(sc);
+}
+
+// =============================================================================================
+// device-resident graph traversal
+// =============================================================================================
+int fvdb_graph_create(fvdb_store* s, fvdb_graph** out) {
+  if (!s || !out) return FVDB_E_INVALID;
+  *out = nullptr;
+  fvdb_graph* g = new (std::nothrow) fvdb_graph();
+  if (!g) return FVDB_E_OOM;
+  g->store = s;
+  *out = g;
+  return FVDB_OK;
+}
+
+void fvdb_graph_destroy(fvdb_graph* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->store->ctx->device);
+  (void)hipStreamSynchronize(g->store->ctx->stream);
+  DBuf* bufs[] = {&g->d_level, &g->d_deleted, &g->d_slot_of, &g->d_slot_start, &g->d_adj, &g->s_q, &g->s_visited, &g->s_touched};
+  for (DBuf* b : bufs) b->release();
+  delete g;
+}
+
+int fvdb_graph_upload(fvdb_graph* g, uint32_t n, const uint32_t* levels, const uint8_t* deleted,
+                      const uint32_t* slot_start, const uint32_t* adj, uint32_t entry_node) {
+  fvdb_ctx* ctx = g->store->ctx;
+  if (n == 0 || n > g->store->rows || entry_node >= n) FAIL(ctx, FVDB_E_INVALID, "graph does not match the store");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<uint32_t> slot_of(n), del32(n);
+  uint32_t slots = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    slot_of[i] = slots;
+    slots += levels[i] + 1;
+    del32[i] = deleted ? deleted[i] : 0;
+  }
+  for (uint32_t sidx = 0; sidx < slots; ++sidx)
+    if (slot_start[sidx + 1] - slot_start[sidx] > 64) FAIL(ctx, FVDB_E_UNSUPPORTED, "neighbour list longer than 64");
+  const uint32_t edges = slot_start[slots];
+  HIPCHK(ctx, g->d_level.ensure((size_t)n * 4));
+  HIPCHK(ctx, g->d_deleted.ensure((size_t)n * 4));
+  HIPCHK(ctx, g->d_slot_of.ensure((size_t)n * 4));
+  HIPCHK(ctx, g->d_slot_start.ensure((size_t)(slots + 1) * 4));
+  HIPCHK(ctx, g->d_adj.ensure(std::max<size_t>(edges, 1) * 4));
+  HIPCHK(ctx, hipMemcpyAsync(g->d_level.p, levels, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(g->d_deleted.p, del32.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(g->d_slot_of.p, slot_of.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(g->d_slot_start.p, slot_start, (size_t)(slots + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (edges) HIPCHK(ctx, hipMemcpyAsync(g->d_adj.p, adj, (size_t)edges * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  g->n = n;
+  g->entry = entry_node;
+  g->top_level = levels[entry_node];
+  g->n_slots = slots;
+  g->uploaded = true;
+  g->vis_B = 0;  // node count may have changed: re-size (and re-zero) the visited bitmaps
+  return FVDB_OK;
+}
+
+int fvdb_graph_set_deleted(fvdb_graph* g, uint32_t node, int deleted) {
+  fvdb_ctx* ctx = g->store->ctx;
+  if (!g->uploaded || node >= g->n) FAIL(ctx, FVDB_E_NOT_FOUND, "no such node");
+  const uint32_t v = deleted ? 1u : 0u;
+  HIPCHK(ctx, hipMemcpyAsync(g->d_deleted.as<uint32_t>() + node, &v, 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+
+int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_t k, uint32_t ef,
+                          uint32_t* out_nodes_dev, float* out_dist_dev, uint32_t* out_counts_dev,
+                          uint32_t* out_status_dev) {
+  fvdb_store* s = g->store;
+  fvdb_ctx* ctx = s->ctx;
+  if (!g->uploaded) FAIL(ctx, FVDB_E_INVALID, "graph not uploaded");
+  if (k == 0 || ef == 0 || ef > 4096) FAIL(ctx, FVDB_E_UNSUPPORTED, "ef must be in 1..4096");
+  if (B == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const float* qd = q_dev;
+  if (s->d != s->dpad) {
+    HIPCHK(ctx, g->s_q.ensure((size_t)B * s->dpad * 4));
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv((uint64_t)B * s->dpad, 256)), dim3(256), 0, ctx->stream, q_dev, s->d,
+                       s->dpad, (uint64_t)B, g->s_q.as<float>());
+    qd = g->s_q.as<float>();
+  }
+  // visited-log capacity per query (FVDB_GRAPH_TCAP: test hook that forces the overflow -> host-walk fallback)
+  const uint32_t words = (g->n + 31) / 32;
+  const uint32_t tcap = getenv("FVDB_GRAPH_TCAP") ? std::max(1, atoi(getenv("FVDB_GRAPH_TCAP"))) : 8192;
+  if (B > g->vis_B || words != g->vis_words || tcap != g->vis_tcap) {  // bitmaps are left all-zero by every search: zero once
+    HIPCHK(ctx, g->s_visited.ensure((size_t)B * words * 4));
+    HIPCHK(ctx, hipMemsetAsync(g->s_visited.p, 0, g->s_visited.cap, ctx->stream));
+    HIPCHK(ctx, g->s_touched.ensure((size_t)B * tcap * 4));
+    g->vis_B = B;
+    g->vis_words = words;
+    g->vis_tcap = tcap;
+  }
+  const uint32_t cand_cap = std::max<uint32_t>(1024, 8 * ef);
+  const size_t lds = graph_lds_bytes(s->dpad, ef, cand_cap);
+  if (lds > 160 * 1024) FAIL(ctx, FVDB_E_UNSUPPORTED, "dimension / ef too large for the on-chip traversal state");
+  if (lds > 48 * 1024)
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)hnsw_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  GraphView gv{s->data, g->d_level.as<uint32_t>(), g->d_deleted.as<uint32_t>(), g->d_slot_of.as<uint32_t>(),
+               g->d_slot_start.as<uint32_t>(), g->d_adj.as<uint32_t>(), g->n, s->dpad, g->entry, g->top_level};
+  hipLaunchKernelGGL(hnsw_search_kernel, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
+                     g->s_visited.as<uint32_t>(), words, g->s_touched.as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
+                     out_counts_dev, out_status_dev);
+  HIPCHK(ctx, hipGetLastError());
+  return FVDB_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,337 @@
+// kernels_graph.h — HNSW search with the traversal resident on the GPU: one wavefront per query
+// walks the graph mirrored in HBM (CSR adjacency), so a whole batch search is ONE launch instead of
+// one launch + host round trip per hop.
+//
+// It executes HNSWIndex::search (src/hnsw/core.rs:398-467) and search_layer (:469-554) operation
+// for operation: the two heaps are std::collections::BinaryHeap restated (sift_up /
+// sift_down_to_bottom, driven by lane 0 so the order of heap operations — and therefore the
+// outcome of exact distance ties — is the reference's); a popped node's neighbours are filtered
+// through the visited set in list order; their distances are the reference's sequential f32 fold
+// (one lane per neighbour, rows staged through LDS with coalesced loads); the admission rule
+// (:517-531) is applied in neighbour order.  Results equal the host-side walk's bit for bit
+// (tests/test_gpu_host_mirror.py::test_device_traversal_*).
+#pragma once
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace fvdb {
+
+struct GraphView {
+  const float* rows;          // [n][dpad] row-major vectors (fvdb_store)
+  const uint32_t* level;      // [n]
+  const uint32_t* deleted;    // [n] 0/1
+  const uint32_t* slot_of;    // [n] index of the node's layer-0 slot
+  const uint32_t* slot_start; // [slots+1] offsets into adj
+  const uint32_t* adj;        // neighbour node indices, list order
+  uint32_t n, dpad, entry, top_level;
+};
+
+struct HItem {
+  uint32_t node;
+  float d;
+};
+
+// SearchCandidate::cmp (src/hnsw/core.rs:126-137): reversed on distance
+__device__ __forceinline__ bool h_le(const HItem a, const HItem b) { return a.d >= b.d; }
+
+__device__ __forceinline__ void h_sift_up(HItem* h, uint32_t start, uint32_t pos) {
+  const HItem elt = h[pos];
+  while (pos > start) {
+    const uint32_t parent = (pos - 1) >> 1;
+    if (h_le(elt, h[parent])) break;
+    h[pos] = h[parent];
+    pos = parent;
+  }
+  h[pos] = elt;
+}
+__device__ __forceinline__ void h_push(HItem* h, uint32_t& n, const HItem c) {
+  h[n] = c;
+  h_sift_up(h, 0, n);
+  n += 1;
+}
+__device__ __forceinline__ HItem h_pop(HItem* h, uint32_t& n) {
+  n -= 1;
+  HItem item = h[n];
+  if (n > 0) {
+    const HItem root = h[0];
+    h[0] = item;
+    item = root;
+    const uint32_t end = n;
+    uint32_t pos = 0;
+    const HItem elt = h[0];
+    uint32_t child = 1;
+    const uint32_t lim = end >= 2 ? end - 2 : 0;
+    while (child <= lim) {
+      if (h_le(h[child], h[child + 1])) child += 1;
+      h[pos] = h[child];
+      pos = child;
+      child = 2 * pos + 1;
+    }
+    if (child == end - 1) {
+      h[pos] = h[child];
+      pos = child;
+    }
+    h[pos] = elt;
+    h_sift_up(h, 0, pos);
+  }
+  return item;
+}
+
+constexpr int kTileRows = 16;
+
+// distances of the wave's query (in LDS) to `np` rows listed in pending[], into pdist[]
+__device__ __forceinline__ void score_pending(const GraphView& g, const float* __restrict__ q_lds, float* tile,
+                                              const uint32_t* pending, float* pdist, uint32_t np, int lane) {
+  const uint32_t dpad = g.dpad, d4 = dpad >> 2, S = dpad + 1;  // odd row stride: lanes hit distinct banks
+  for (uint32_t t0 = 0; t0 < np; t0 += kTileRows) {
+    const uint32_t rows = min((uint32_t)kTileRows, np - t0);
+    // coalesced row loads (1 KiB per wave-instruction), 4 rows in flight at a time
+    for (uint32_t r0 = 0; r0 < rows; r0 += 4) {
+      float4 v[4][2];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const uint32_t r = r0 + rr;
+        if (r < rows) {
+          const float4* src = (const float4*)(g.rows + (size_t)pending[t0 + r] * dpad);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t c = lane + 64 * h;
+            if (c < d4) v[rr][h] = src[c];
+          }
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const uint32_t r = r0 + rr;
+        if (r < rows) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t c = lane + 64 * h;
+            if (c < d4) {
+              float* dst = tile + r * S + 4 * c;
+              dst[0] = v[rr][h].x;
+              dst[1] = v[rr][h].y;
+              dst[2] = v[rr][h].z;
+              dst[3] = v[rr][h].w;
+            }
+          }
+        }
+      }
+      for (uint32_t c = 128 + lane; c < d4; c += 64) {  // d > 512: remaining chunks, row by row
+        for (uint32_t r = r0; r < min(r0 + 4, rows); ++r) {
+          const float4 w = ((const float4*)(g.rows + (size_t)pending[t0 + r] * dpad))[c];
+          float* dst = tile + r * S + 4 * c;
+          dst[0] = w.x;
+          dst[1] = w.y;
+          dst[2] = w.z;
+          dst[3] = w.w;
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // the wave's LDS writes land before its reads
+    __builtin_amdgcn_wave_barrier();
+    if ((uint32_t)lane < rows) {  // one lane per row: the reference's left-to-right f32 fold
+      const float* x = tile + lane * S;
+      float acc = 0.0f;
+      for (uint32_t j = 0; j < dpad; j += 4) {
+        const float4 qv = *(const float4*)(q_lds + j);  // same address in every lane: LDS broadcast
+        float t;
+        t = qv.x - x[j + 0]; acc = acc + t * t;
+        t = qv.y - x[j + 1]; acc = acc + t * t;
+        t = qv.z - x[j + 2]; acc = acc + t * t;
+        t = qv.w - x[j + 3]; acc = acc + t * t;
+      }
+      pdist[t0 + lane] = sqrtf(acc);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// LDS carve-up per wave (bytes): q [dpad*4] | tile [16*(dpad+1)*4] | pending [64*4] | pdist [64*4] |
+// scalars [16*4] | near [(ef+1)*8] | res [ef*8] | cand [cand_cap*8]
+__host__ __device__ inline size_t graph_lds_bytes(uint32_t dpad, uint32_t ef, uint32_t cand_cap) {
+  size_t b = (size_t)dpad * 4 + (size_t)kTileRows * (dpad + 1) * 4 + 64 * 4 + 64 * 4 + 16 * 4;
+  b = (b + 7) & ~(size_t)7;
+  b += (size_t)(ef + 2) * 8 + (size_t)(ef + 1) * 8 + (size_t)cand_cap * 8;
+  return (b + 15) & ~(size_t)15;
+}
+
+__global__ __launch_bounds__(64) void hnsw_search_kernel(const GraphView g, const float* __restrict__ queries,
+                                                         uint32_t B, uint32_t k, uint32_t ef_final, uint32_t cand_cap,
+                                                         uint32_t* __restrict__ visited /* [B][words] zero on entry */,
+                                                         uint32_t words, uint32_t* __restrict__ touched /* [B][tcap] */,
+                                                         uint32_t tcap, uint32_t* __restrict__ out_nodes,
+                                                         float* __restrict__ out_dist, uint32_t* __restrict__ out_counts,
+                                                         uint32_t* __restrict__ out_status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x;
+  const uint32_t b = blockIdx.x;
+  if (b >= B) return;
+  const uint32_t dpad = g.dpad;
+  float* q_lds = (float*)lds;
+  float* tile = q_lds + dpad;
+  uint32_t* pending = (uint32_t*)(tile + kTileRows * (dpad + 1));
+  float* pdist = (float*)(pending + 64);
+  uint32_t* sc = (uint32_t*)(pdist + 64);  // [0] stop, [1] node, [2] status, [3] nN
+  size_t off = ((size_t)((unsigned char*)(sc + 16) - lds) + 7) & ~(size_t)7;
+  HItem* near = (HItem*)(lds + off);
+  HItem* res = near + (ef_final + 2);
+  HItem* cand = res + (ef_final + 1);
+  uint32_t* vis = visited + (size_t)b * words;
+  uint32_t* tch = touched + (size_t)b * tcap;
+
+  for (uint32_t j = lane; j < dpad; j += 64) q_lds[j] = queries[(size_t)b * dpad + j];
+  if (lane == 0) sc[2] = 0;
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+
+  // nearest = [(entry, dist(q, entry))]  (:432-435)
+  if (lane == 0) pending[0] = g.entry;
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  score_pending(g, q_lds, tile, pending, pdist, 1, lane);
+  uint32_t n_res = 1;
+  if (lane == 0) res[0] = HItem{g.entry, pdist[0]};
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+
+  for (uint32_t layer = g.top_level + 1; layer-- > 0;) {
+    const uint32_t ef = layer == 0 ? ef_final : 1;
+    uint32_t nC = 0, nN = 0, nT = 0;  // lane 0's copies are authoritative
+    bool overflow = false;
+    // ---- search_layer(query, res[0].node, ef, layer) ----
+    const HItem ep = res[0];
+    if (lane == 0) {
+      h_push(cand, nC, ep);
+      h_push(near, nN, HItem{ep.node, -ep.d});
+      atomicOr(&vis[ep.node >> 5], 1u << (ep.node & 31));
+      tch[0] = ep.node;
+    }
+    nT = 1;
+    for (;;) {
+      if (lane == 0) {
+        uint32_t stop = 0, node = 0;
+        if (nC == 0) {
+          stop = 1;
+        } else {
+          const HItem cur = h_pop(cand, nC);
+          if (cur.d > -near[0].d) stop = 1;  // :499-501
+          node = cur.node;
+        }
+        sc[0] = stop;
+        sc[1] = node;
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t stop = sc[0], node = sc[1];
+      if (stop) break;
+      uint32_t np = 0;
+      if (g.level[node] >= layer) {
+        const uint32_t s = g.slot_of[node] + layer;
+        const uint32_t a0 = g.slot_start[s], cnt = g.slot_start[s + 1] - a0;  // cnt <= 64 (host checks the degree cap)
+        uint32_t nb = 0;
+        bool fresh = false, keep = false;
+        if ((uint32_t)lane < cnt) {
+          nb = g.adj[a0 + lane];
+          const uint32_t bit = 1u << (nb & 31);
+          fresh = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;  // visited.insert (:506-507)
+          keep = fresh && g.deleted[nb] == 0;                  // :511-513
+        }
+        const uint64_t fm = __ballot(fresh), km = __ballot(keep);
+        const uint64_t lt = (1ull << lane) - 1;
+        const uint32_t nf = __popcll(fm);
+        if (nT + nf > tcap) {
+          overflow = true;
+        } else if (fresh) {
+          tch[nT + __popcll(fm & lt)] = nb;
+        }
+        nT += nf;
+        np = __popcll(km);
+        if (keep) pending[__popcll(km & lt)] = nb;  // list order preserved
+      }
+      if (overflow) break;
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      if (np) {
+        score_pending(g, q_lds, tile, pending, pdist, np, lane);
+        if (lane == 0) {
+          for (uint32_t i = 0; i < np; ++i) {  // admission rule :517-531, neighbour order
+            const float d = pdist[i];
+            if (d < -near[0].d || nN < ef) {
+              if (nC >= cand_cap) {
+                sc[2] = 1;
+                break;
+              }
+              h_push(cand, nC, HItem{pending[i], d});
+              h_push(near, nN, HItem{pending[i], -d});
+              if (nN > ef) (void)h_pop(near, nN);
+            }
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (sc[2]) {
+          overflow = true;
+          break;
+        }
+      }
+    }
+    // ---- result of the layer: nearest in heap order, stable-sorted by distance (:541-553) ----
+    if (lane == 0) sc[3] = nN;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nn = sc[3];
+    if (!overflow) {
+      for (uint32_t i0 = 0; i0 < nn; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        if (i < nn) {
+          const HItem me = near[i];
+          const float md = -me.d;
+          uint32_t rank = 0;
+          for (uint32_t j = 0; j < nn; ++j) {
+            const float dj = -near[j].d;
+            rank += (dj < md || (dj == md && j < i)) ? 1u : 0u;
+          }
+          res[rank] = HItem{me.node, md};
+        }
+      }
+      n_res = nn;
+    }
+    // ---- drop this layer's visited set ----
+    if (nT <= tcap && !overflow) {
+      for (uint32_t i = lane; i < nT; i += 64) vis[tch[i] >> 5] = 0;
+    } else {
+      for (uint32_t w = lane; w < words; w += 64) vis[w] = 0;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (overflow) {
+      if (lane == 0) {
+        out_status[b] = 1;
+        out_counts[b] = 0;
+      }
+      return;
+    }
+  }
+  // ---- filter deleted, take k (:451-466) ----
+  if (lane == 0) {
+    uint32_t w = 0;
+    for (uint32_t i = 0; i < n_res && w < k; ++i) {
+      const HItem c = res[i];
+      if (g.deleted[c.node]) continue;
+      out_nodes[(size_t)b * k + w] = c.node;
+      out_dist[(size_t)b * k + w] = c.d;
+      ++w;
+    }
+    out_counts[b] = w;
+    out_status[b] = 0;
+    for (uint32_t i = w; i < k; ++i) {
+      out_nodes[(size_t)b * k + i] = 0xFFFFFFFFu;
+      out_dist[(size_t)b * k + i] = __uint_as_float(0x7F800000u);
+    }
+  }
+}
+
+}  // namespace fvdb

@@ -108,6 +108,9 @@ int fvh_hnsw_get_vector(void* p, uint64_t id, float* out) {
 uint64_t fvh_hnsw_dist_evals(void* p) { return ((HNSWIndex*)p)->dist_evals(); }
 uint64_t fvh_hnsw_hops(void* p) { return ((HNSWIndex*)p)->hops(); }
 void fvh_hnsw_set_threads(void* p, int t) { ((HNSWIndex*)p)->set_threads(t); }
+void fvh_hnsw_set_device_traversal(void* p, int on) { ((HNSWIndex*)p)->set_device_traversal(on != 0); }
+int fvh_hnsw_device_traversal(void* p) { return ((HNSWIndex*)p)->device_traversal(); }
+uint64_t fvh_hnsw_device_fallbacks(void* p) { return ((HNSWIndex*)p)->device_fallbacks(); }
 uint32_t fvh_hnsw_dimension(void* p) { return ((HNSWIndex*)p)->dimension(); }
 
 // ---- HybridIndex ----

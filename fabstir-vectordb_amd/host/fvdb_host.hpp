@@ -157,6 +157,12 @@ class HNSWIndex {
   uint64_t dist_evals() const { return n_dist_; }
   uint64_t hops() const { return n_hops_; }
   void set_threads(int t) { threads_ = t; }
+  // Where the layered walk runs for batch searches: false = on the host, every hop's candidates scored
+  // by one GPU launch (fvdb_scorer_*); true (default) = entirely on the GPU (fvdb_graph_search_dev), the
+  // graph mirrored in HBM.  Same results; inserts always use the host walk.
+  void set_device_traversal(bool on) { device_traversal_ = on; }
+  bool device_traversal() const { return device_traversal_; }
+  uint64_t device_fallbacks() const { return n_fallback_; }
 
  private:
   struct Query {
@@ -200,6 +206,16 @@ class HNSWIndex {
   void lane_advance(Lane& ln, const float* q, bool q_on_device, uint32_t ef_final, uint64_t* ids, float* dist,
                     uint32_t* counts);
   std::vector<Lane> lanes_;
+  int sync_graph();
+  int search_on_device(const float* q_dev, uint32_t B, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
+                       uint32_t* counts, std::vector<uint32_t>& failed);
+  int search_host_walk(const float* q, bool q_on_device, uint32_t B, uint32_t k, uint32_t ef, uint64_t* ids,
+                       float* dist, uint32_t* counts);
+  fvdb_graph* graph_ = nullptr;
+  bool graph_dirty_ = true, device_traversal_ = true;
+  void *d_res_nodes_ = nullptr, *d_res_dist_ = nullptr, *d_res_cnt_ = nullptr, *d_res_status_ = nullptr, *d_q_ = nullptr;
+  uint64_t d_res_cap_ = 0, d_q_cap_ = 0;
+  uint64_t n_fallback_ = 0;
 
   fvdb_ctx* ctx_;
   HNSWConfig cfg_;

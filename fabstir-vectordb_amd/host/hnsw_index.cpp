@@ -136,6 +136,10 @@ static inline bool set_insert(std::vector<uint32_t>& s, uint32_t v) {
 HNSWIndex::HNSWIndex(fvdb_ctx* ctx, const HNSWConfig& cfg) : ctx_(ctx), cfg_(cfg), rng_(cfg.seed) {}
 
 HNSWIndex::~HNSWIndex() {
+  if (graph_) fvdb_graph_destroy(graph_);
+  void* bufs[] = {d_res_nodes_, d_res_dist_, d_res_cnt_, d_res_status_, d_q_};
+  for (void* b : bufs)
+    if (b) fvdb_dev_free(ctx_, b);
   for (auto& ln : lanes_)
     if (ln.sc) fvdb_scorer_destroy(ln.sc);
   if (scorer_) fvdb_scorer_destroy(scorer_);
@@ -201,6 +205,7 @@ int HNSWIndex::mark_deleted(uint64_t id) {
   auto it = index_of_.find(id);
   if (it == index_of_.end()) return FVDB_E_NOT_FOUND;
   deleted_[it->second] = 1;
+  if (graph_ && !graph_dirty_) fvdb_graph_set_deleted(graph_, it->second, 1);
   return FVDB_OK;
 }
 bool HNSWIndex::is_deleted(uint64_t id) const {
@@ -503,6 +508,70 @@ void HNSWIndex::lane_advance(Lane& ln, const float* q, bool q_on_device, uint32_
   ln.done = true;
 }
 
+// mirror the adjacency lists into HBM (only when they changed)
+int HNSWIndex::sync_graph() {
+  if (!graph_) {
+    int rc = fvdb_graph_create(store_, &graph_);
+    if (rc) return rc;
+  }
+  if (!graph_dirty_) return FVDB_OK;
+  const uint32_t n = (uint32_t)ids_.size();
+  std::vector<uint32_t> slot_start, adj;
+  slot_start.reserve(graph_slots() + 1);
+  adj.reserve(graph_edges());
+  for (uint32_t i = 0; i < n; ++i)
+    for (uint32_t l = 0; l <= level_[i]; ++l) {
+      slot_start.push_back((uint32_t)adj.size());
+      adj.insert(adj.end(), nbrs_[i][l].begin(), nbrs_[i][l].end());
+    }
+  slot_start.push_back((uint32_t)adj.size());
+  int rc = fvdb_graph_upload(graph_, n, level_.data(), deleted_.data(), slot_start.data(), adj.data(), entry_);
+  if (rc) return rc;
+  graph_dirty_ = false;
+  return FVDB_OK;
+}
+
+// whole batch in one launch; queries the kernel could not finish on chip are listed in `failed`
+int HNSWIndex::search_on_device(const float* q_dev, uint32_t B, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
+                                uint32_t* counts, std::vector<uint32_t>& failed) {
+  int rc = sync_graph();
+  if (rc) return rc;
+  const uint64_t need = (uint64_t)B * std::max<uint32_t>(k, 1);
+  if (need > d_res_cap_) {
+    void** bufs[] = {&d_res_nodes_, &d_res_dist_, &d_res_cnt_, &d_res_status_};
+    for (void** b : bufs) {
+      if (*b) fvdb_dev_free(ctx_, *b);
+      *b = nullptr;
+    }
+    d_res_cap_ = 0;
+    if (fvdb_dev_alloc(ctx_, need * 4, &d_res_nodes_) || fvdb_dev_alloc(ctx_, need * 4, &d_res_dist_) ||
+        fvdb_dev_alloc(ctx_, need * 4, &d_res_cnt_) || fvdb_dev_alloc(ctx_, need * 4, &d_res_status_))
+      return FVDB_E_OOM;
+    d_res_cap_ = need;
+  }
+  rc = fvdb_graph_search_dev(graph_, q_dev, B, k, ef, (uint32_t*)d_res_nodes_, (float*)d_res_dist_,
+                             (uint32_t*)d_res_cnt_, (uint32_t*)d_res_status_);
+  if (rc) return rc;
+  std::vector<uint32_t> nodes((size_t)B * k), status(B);
+  rc = fvdb_dev_download(ctx_, nodes.data(), d_res_nodes_, (size_t)B * k * 4);
+  if (!rc) rc = fvdb_dev_download(ctx_, dist, d_res_dist_, (size_t)B * k * 4);
+  if (!rc) rc = fvdb_dev_download(ctx_, counts, d_res_cnt_, (size_t)B * 4);
+  if (!rc) rc = fvdb_dev_download(ctx_, status.data(), d_res_status_, (size_t)B * 4);
+  if (rc) return rc;
+  for (uint32_t b = 0; b < B; ++b) {
+    if (status[b]) {
+      failed.push_back(b);
+      counts[b] = 0;
+      continue;
+    }
+    for (uint32_t i = 0; i < k; ++i) {
+      const uint32_t nd = nodes[(size_t)b * k + i];
+      ids[(size_t)b * k + i] = i < counts[b] ? ids_[nd] : FVDB_NO_ID;
+    }
+  }
+  return FVDB_OK;
+}
+
 int HNSWIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef,
                            uint64_t* ids, float* dist, uint32_t* counts) {
   for (uint32_t b = 0; b < B; ++b) counts[b] = 0;
@@ -512,7 +581,60 @@ int HNSWIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint32_
   }
   if (!has_entry_) return FVDB_OK;  // empty index -> empty results (:404-407)
   if (has_dim_ && dim != dim_) return FVDB_E_DIM;
-  if (B == 0) return FVDB_OK;
+  if (B == 0 || k == 0) return FVDB_OK;
+  static const bool env_off = getenv("FVDB_HNSW_DEVICE") && atoi(getenv("FVDB_HNSW_DEVICE")) == 0;
+  const uint32_t maxdeg = std::max(cfg_.max_connections, cfg_.max_connections_layer_0);
+  if (!device_traversal_ || env_off || maxdeg + 1 > 64 || ef > 4096)
+    return search_host_walk(q, q_on_device, B, k, ef, ids, dist, counts);
+  const float* qd = q;
+  if (!q_on_device) {  // stage the batch in HBM
+    const uint64_t bytes = (uint64_t)B * dim * 4;
+    if (bytes > d_q_cap_) {
+      if (d_q_) fvdb_dev_free(ctx_, d_q_);
+      d_q_ = nullptr;
+      d_q_cap_ = 0;
+      if (fvdb_dev_alloc(ctx_, bytes, &d_q_)) return FVDB_E_OOM;
+      d_q_cap_ = bytes;
+    }
+    int rc = fvdb_dev_upload(ctx_, d_q_, q, bytes);
+    if (rc) return rc;
+    qd = (const float*)d_q_;
+  }
+  std::vector<uint32_t> failed;
+  int rc = search_on_device(qd, B, k, ef, ids, dist, counts, failed);
+  if (rc) return rc;
+  if (!failed.empty()) {  // rare: on-chip heap / visited log overflow -> host walk for those queries
+    n_fallback_ += failed.size();
+    std::vector<float> hq((size_t)failed.size() * dim);
+    for (size_t i = 0; i < failed.size(); ++i) {
+      if (q_on_device) {
+        rc = fvdb_dev_download(ctx_, &hq[i * dim], q + (size_t)failed[i] * dim, (size_t)dim * 4);
+        if (rc) return rc;
+      } else {
+        std::memcpy(&hq[i * dim], q + (size_t)failed[i] * dim, (size_t)dim * 4);
+      }
+    }
+    std::vector<uint64_t> fi(failed.size() * (size_t)k);
+    std::vector<float> fd(failed.size() * (size_t)k);
+    std::vector<uint32_t> fc(failed.size());
+    rc = search_host_walk(hq.data(), false, (uint32_t)failed.size(), k, ef, fi.data(), fd.data(), fc.data());
+    if (rc) return rc;
+    for (size_t i = 0; i < failed.size(); ++i) {
+      std::memcpy(ids + (size_t)failed[i] * k, &fi[i * k], (size_t)k * 8);
+      std::memcpy(dist + (size_t)failed[i] * k, &fd[i * k], (size_t)k * 4);
+      counts[failed[i]] = fc[i];
+    }
+  }
+  return FVDB_OK;
+}
+
+int HNSWIndex::search_host_walk(const float* q, bool q_on_device, uint32_t B, uint32_t k, uint32_t ef, uint64_t* ids,
+                                float* dist, uint32_t* counts) {
+  for (uint32_t b = 0; b < B; ++b) counts[b] = 0;
+  for (size_t i = 0; i < (size_t)B * k; ++i) {
+    ids[i] = FVDB_NO_ID;
+    dist[i] = __builtin_huge_valf();
+  }
   static const int auto_threads = usable_cpus();
   const int nt = std::max(1, threads_ > 0 ? threads_ : auto_threads);
   const uint32_t maxdeg = std::max(cfg_.max_connections, cfg_.max_connections_layer_0) + 1;
@@ -671,6 +793,7 @@ int HNSWIndex::insert(uint64_t id, const float* v, uint32_t dim, int64_t forced_
   index_of_[id] = row;
   registered_[row] = 1;
   n_registered_ += 1;
+  graph_dirty_ = true;
   if (!is_first && level > entry_level) entry_ = row;  // :372-375
   return FVDB_OK;
 }
@@ -714,6 +837,7 @@ int HNSWIndex::restore(const uint64_t* ids, const float* v, uint64_t n, uint32_t
   if (it == index_of_.end()) return FVDB_E_NOT_FOUND;
   entry_ = it->second;
   has_entry_ = true;
+  graph_dirty_ = true;
   return FVDB_OK;
 }
 
@@ -826,6 +950,7 @@ int HNSWIndex::bulk_build(const uint64_t* ids, const float* v, uint64_t n, uint3
     fvdb_ivf_destroy(flat);
     if (rc) return rc;
   }
+  graph_dirty_ = true;
   return FVDB_OK;
 }
 

@@ -63,6 +63,9 @@ HOST_SIGNATURES = {
     "fvh_hnsw_hops": (u64, [vp]),
     "fvh_hnsw_set_threads": (None, [vp, i32]),
     "fvh_hnsw_dimension": (u32, [vp]),
+    "fvh_hnsw_set_device_traversal": (None, [vp, i32]),
+    "fvh_hnsw_device_traversal": (i32, [vp]),
+    "fvh_hnsw_device_fallbacks": (u64, [vp]),
     "fvh_hybrid_new": (vp, [vp, vp, dbl, u64, i32, u64, u32, u32, u32, u64, u32, u32, u32, u32, u64]),
     "fvh_hybrid_free": (None, [vp]),
     "fvh_hybrid_initialize": (i32, [vp, f32p, u64, u32]),
@@ -362,6 +365,17 @@ class HNSWIndex(_Base):
 
     def set_threads(self, t):
         self.lib.fvh_hnsw_set_threads(self.h, int(t))
+
+    def set_device_traversal(self, on):
+        """True (default): the layered walk runs on the GPU (one launch per batch); False: on the host
+        with one scoring launch per hop (the north_star's split).  Results are identical."""
+        self.lib.fvh_hnsw_set_device_traversal(self.h, int(bool(on)))
+
+    def device_traversal(self):
+        return bool(self.lib.fvh_hnsw_device_traversal(self.h))
+
+    def device_fallbacks(self):
+        return int(self.lib.fvh_hnsw_device_fallbacks(self.h))
 
 
 class HybridIndex(_Base):

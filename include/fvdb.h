@@ -187,6 +187,27 @@ int fvdb_scorer_run(fvdb_scorer* sc, uint32_t B, uint32_t C); /* scores cand_buf
 int fvdb_scorer_launch(fvdb_scorer* sc, uint32_t B, uint32_t C);
 int fvdb_scorer_wait(fvdb_scorer* sc);
 
+/* ---- device-resident graph traversal --------------------------------------------------------
+ * Optional fast path for HNSWIndex::search (src/hnsw/core.rs:398-554): the adjacency lists are
+ * mirrored in HBM and one wavefront per query runs the whole layered search in a single launch
+ * (same heaps, same visiting order, same distance arithmetic => same results as the host walk that
+ * uses fvdb_scorer_*).  Rows are the store's; node index = store row.
+ */
+typedef struct fvdb_graph fvdb_graph;
+int fvdb_graph_create(fvdb_store* s, fvdb_graph** out);
+void fvdb_graph_destroy(fvdb_graph* g);
+/* levels[n]; deleted[n] (0/1); slot_start[n_slots+1] / adj[]: CSR over (node, layer) slots in node
+ * order, layer 0 first (n_slots = sum(level+1)); every list must hold <= 64 neighbours. */
+int fvdb_graph_upload(fvdb_graph* g, uint32_t n, const uint32_t* levels, const uint8_t* deleted,
+                      const uint32_t* slot_start, const uint32_t* adj, uint32_t entry_node);
+int fvdb_graph_set_deleted(fvdb_graph* g, uint32_t node, int deleted);
+/* B queries (device, B x d).  out_nodes/out_dist: B x k device buffers, out_counts/out_status: B.
+ * status 1 = the query overflowed the on-chip candidate heap / visited log and must be searched
+ * through the host walk instead (its count is 0). */
+int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_t k, uint32_t ef,
+                          uint32_t* out_nodes_dev, float* out_dist_dev, uint32_t* out_counts_dev,
+                          uint32_t* out_status_dev);
+
 #ifdef __cplusplus
 }
 #endif

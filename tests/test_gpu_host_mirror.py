@@ -161,6 +161,67 @@ def test_hnsw_bulk_build_and_restore_parity(fv, ctx):
     assert hits / (10 * q.shape[0]) > 0.8
 
 
+def test_device_traversal_equals_host_walk_and_oracle(fv, ctx):
+    # the layered walk on the GPU (one launch per batch) vs the host walk (one scoring launch per hop)
+    n, d = 2500, 40
+    x = mixture(n, d, n_comp=6, sigma=1.0, seed=61)
+    ids = np.arange(n, dtype=np.uint64) * 5 + 2
+    gh = fv.HNSWIndex(ctx, 16, 32, 200, seed=13)
+    gh.bulk_build(ids, x)
+    gi, lv, off, nb = gh.export_graph()
+    oh = orc.HNSWIndex(16, 32, 200, seed=13)
+    oh.restore(gi, x, lv, off, nb, gh.entry_point())
+    for i in (7, 99, 1500, 2499):
+        gh.mark_deleted(int(ids[i]))
+        oh.mark_deleted(int(ids[i]))
+    q = np.concatenate([mixture(90, d, n_comp=6, sigma=1.0, seed=62), x[[7, 99, 300]]])
+    assert gh.device_traversal()
+    for k, ef in ((10, 50), (1, 1), (10, 10), (40, 200), (5, 333)):
+        dev = gh.search(q, k, ef)
+        gh.set_device_traversal(False)
+        host = gh.search(q, k, ef)
+        gh.set_device_traversal(True)
+        assert np.array_equal(dev.counts, host.counts) and np.array_equal(dev.ids, host.ids)
+        assert np.array_equal(bits(dev.distances), bits(host.distances))
+        assert_same_results(dev, *oh.batch_search(q, k, ef))
+    assert gh.device_fallbacks() == 0
+
+
+def test_device_traversal_duplicate_vectors_tie_order(fv, ctx):
+    # exact distance ties exercise the restated BinaryHeap order inside the kernel
+    d = 6
+    base = mixture(60, d, n_comp=3, sigma=1.0, seed=63)
+    x = np.concatenate([base, base, base])
+    ids = np.arange(x.shape[0], dtype=np.uint64)
+    levels = orc.rng_levels(5, x.shape[0])
+    gh, oh = fv.HNSWIndex(ctx, 6, 12, 40, seed=5), orc.HNSWIndex(6, 12, 40, seed=5)
+    gh.batch_insert(ids, x, levels)
+    oh.batch_insert(ids, x, levels)
+    same_graph(gh, oh, ids)
+    q = base[:30] + np.float32(0.001)
+    for k, ef in ((9, 30), (20, 60)):
+        assert_same_results(gh.search(q, k, ef), *oh.batch_search(q, k, ef))
+
+
+def test_device_traversal_overflow_falls_back_to_host_walk(fv, ctx, monkeypatch):
+    n, d = 1200, 12
+    x = mixture(n, d, n_comp=4, sigma=1.0, seed=64)
+    ids = np.arange(n, dtype=np.uint64)
+    gh = fv.HNSWIndex(ctx, 8, 16, 60, seed=9)
+    gh.bulk_build(ids, x)
+    q = mixture(33, d, n_comp=4, sigma=1.0, seed=65)
+    gh.set_device_traversal(False)
+    want = gh.search(q, 10, 100)
+    gh.set_device_traversal(True)
+    monkeypatch.setenv("FVDB_GRAPH_TCAP", "40")  # visited log of 40 nodes: every query overflows
+    got = gh.search(q, 10, 100)
+    assert gh.device_fallbacks() == q.shape[0]
+    assert np.array_equal(got.ids, want.ids) and np.array_equal(bits(got.distances), bits(want.distances))
+    monkeypatch.delenv("FVDB_GRAPH_TCAP")
+    again = gh.search(q, 10, 100)  # bitmaps were left clean by the aborted walks
+    assert np.array_equal(again.ids, want.ids) and gh.device_fallbacks() == q.shape[0]
+
+
 # ---- IVFIndex mirror -----------------------------------------------------------------------
 TRAIN9 = [[0.0, 0.0], [0.1, 0.1], [0.2, -0.1], [5.0, 5.0], [5.1, 4.9], [4.9, 5.1],
           [-5.0, -5.0], [-4.9, -5.1], [-5.1, -4.9]]
