@@ -134,6 +134,7 @@ __device__ __forceinline__ void score_pending(const GraphView& g, const float* _
     if ((uint32_t)lane < rows) {  // one lane per row: the reference's left-to-right f32 fold
       const float* x = tile + lane * S;
       float acc = 0.0f;
+#pragma unroll 8
       for (uint32_t j = 0; j < dpad; j += 4) {
         const float4 qv = *(const float4*)(q_lds + j);  // same address in every lane: LDS broadcast
         float t;

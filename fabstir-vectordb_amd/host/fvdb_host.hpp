@@ -137,6 +137,12 @@ class HNSWIndex {
              uint32_t* counts);                                                    // :398 (batched, lock-step hops)
   int search_dev(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
                  uint32_t* counts);  // queries resident in HBM, results to host
+  // Split form for callers that overlap other GPU work with the graph walk: begin enqueues the
+  // device-resident traversal (returns false when this search has to use the host walk instead, in which
+  // case nothing was enqueued), end waits for it and delivers the results.
+  bool search_dev_begin(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, int* rc);
+  int search_dev_end(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
+                     uint32_t* counts);
   int mark_deleted(uint64_t id);                                                   // operations.rs:127
   bool is_deleted(uint64_t id) const;
   uint64_t active_count() const;
@@ -207,8 +213,11 @@ class HNSWIndex {
                     uint32_t* counts);
   std::vector<Lane> lanes_;
   int sync_graph();
-  int search_on_device(const float* q_dev, uint32_t B, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
-                       uint32_t* counts, std::vector<uint32_t>& failed);
+  bool device_path_ok(uint32_t ef) const;
+  int device_launch(const float* q_dev, uint32_t B, uint32_t k, uint32_t ef);
+  int device_collect(uint32_t B, uint32_t k, uint64_t* ids, float* dist, uint32_t* counts, std::vector<uint32_t>& failed);
+  int finish_failed(const float* q, bool q_on_device, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
+                    uint32_t* counts, const std::vector<uint32_t>& failed);
   int search_host_walk(const float* q, bool q_on_device, uint32_t B, uint32_t k, uint32_t ef, uint64_t* ids,
                        float* dist, uint32_t* counts);
   fvdb_graph* graph_ = nullptr;
@@ -308,7 +317,12 @@ class HybridIndex {
   bool initialized_ = false, ivf_trained_ = false;
   std::vector<uint64_t> ts_order_;
   std::unordered_map<uint64_t, double> timestamps_;
-  std::vector<uint64_t> pending_migration_;  // ids living in HNSW whose copy into IVF has not succeeded
+  struct Pending {
+    uint64_t id;
+    double ts;
+  };
+  std::vector<Pending> pending_migration_;  // (insertion order) ids living in HNSW not yet copied into IVF
+  double pending_min_ts_ = 1e300;           // oldest timestamp among them: O(1) "nothing is due" test
   uint64_t recent_count_ = 0, historical_count_ = 0;
 };
 

@@ -531,9 +531,14 @@ int HNSWIndex::sync_graph() {
   return FVDB_OK;
 }
 
-// whole batch in one launch; queries the kernel could not finish on chip are listed in `failed`
-int HNSWIndex::search_on_device(const float* q_dev, uint32_t B, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
-                                uint32_t* counts, std::vector<uint32_t>& failed) {
+bool HNSWIndex::device_path_ok(uint32_t ef) const {
+  static const bool env_off = getenv("FVDB_HNSW_DEVICE") && atoi(getenv("FVDB_HNSW_DEVICE")) == 0;
+  const uint32_t maxdeg = std::max(cfg_.max_connections, cfg_.max_connections_layer_0);
+  return device_traversal_ && !env_off && maxdeg + 1 <= 64 && ef <= 4096;
+}
+
+// whole batch in one launch (asynchronous on the context's stream)
+int HNSWIndex::device_launch(const float* q_dev, uint32_t B, uint32_t k, uint32_t ef) {
   int rc = sync_graph();
   if (rc) return rc;
   const uint64_t need = (uint64_t)B * std::max<uint32_t>(k, 1);
@@ -549,11 +554,15 @@ int HNSWIndex::search_on_device(const float* q_dev, uint32_t B, uint32_t k, uint
       return FVDB_E_OOM;
     d_res_cap_ = need;
   }
-  rc = fvdb_graph_search_dev(graph_, q_dev, B, k, ef, (uint32_t*)d_res_nodes_, (float*)d_res_dist_,
-                             (uint32_t*)d_res_cnt_, (uint32_t*)d_res_status_);
-  if (rc) return rc;
+  return fvdb_graph_search_dev(graph_, q_dev, B, k, ef, (uint32_t*)d_res_nodes_, (float*)d_res_dist_,
+                               (uint32_t*)d_res_cnt_, (uint32_t*)d_res_status_);
+}
+
+// wait + fetch; queries the kernel could not finish on chip are listed in `failed`
+int HNSWIndex::device_collect(uint32_t B, uint32_t k, uint64_t* ids, float* dist, uint32_t* counts,
+                              std::vector<uint32_t>& failed) {
   std::vector<uint32_t> nodes((size_t)B * k), status(B);
-  rc = fvdb_dev_download(ctx_, nodes.data(), d_res_nodes_, (size_t)B * k * 4);
+  int rc = fvdb_dev_download(ctx_, nodes.data(), d_res_nodes_, (size_t)B * k * 4);
   if (!rc) rc = fvdb_dev_download(ctx_, dist, d_res_dist_, (size_t)B * k * 4);
   if (!rc) rc = fvdb_dev_download(ctx_, counts, d_res_cnt_, (size_t)B * 4);
   if (!rc) rc = fvdb_dev_download(ctx_, status.data(), d_res_status_, (size_t)B * 4);
@@ -572,6 +581,48 @@ int HNSWIndex::search_on_device(const float* q_dev, uint32_t B, uint32_t k, uint
   return FVDB_OK;
 }
 
+// rare: on-chip heap / visited log overflow -> host walk for those queries
+int HNSWIndex::finish_failed(const float* q, bool q_on_device, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids,
+                             float* dist, uint32_t* counts, const std::vector<uint32_t>& failed) {
+  if (failed.empty()) return FVDB_OK;
+  n_fallback_ += failed.size();
+  std::vector<float> hq((size_t)failed.size() * dim);
+  for (size_t i = 0; i < failed.size(); ++i) {
+    if (q_on_device) {
+      int rc = fvdb_dev_download(ctx_, &hq[i * dim], q + (size_t)failed[i] * dim, (size_t)dim * 4);
+      if (rc) return rc;
+    } else {
+      std::memcpy(&hq[i * dim], q + (size_t)failed[i] * dim, (size_t)dim * 4);
+    }
+  }
+  std::vector<uint64_t> fi(failed.size() * (size_t)k);
+  std::vector<float> fd(failed.size() * (size_t)k);
+  std::vector<uint32_t> fc(failed.size());
+  int rc = search_host_walk(hq.data(), false, (uint32_t)failed.size(), k, ef, fi.data(), fd.data(), fc.data());
+  if (rc) return rc;
+  for (size_t i = 0; i < failed.size(); ++i) {
+    std::memcpy(ids + (size_t)failed[i] * k, &fi[i * k], (size_t)k * 8);
+    std::memcpy(dist + (size_t)failed[i] * k, &fd[i * k], (size_t)k * 4);
+    counts[failed[i]] = fc[i];
+  }
+  return FVDB_OK;
+}
+
+bool HNSWIndex::search_dev_begin(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, int* rc) {
+  *rc = FVDB_OK;
+  if (!has_entry_ || B == 0 || k == 0 || (has_dim_ && dim != dim_) || !device_path_ok(ef)) return false;
+  *rc = device_launch(q_dev, B, k, ef);
+  return *rc == FVDB_OK;
+}
+
+int HNSWIndex::search_dev_end(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids,
+                              float* dist, uint32_t* counts) {
+  std::vector<uint32_t> failed;
+  int rc = device_collect(B, k, ids, dist, counts, failed);
+  if (rc) return rc;
+  return finish_failed(q_dev, true, dim, k, ef, ids, dist, counts, failed);
+}
+
 int HNSWIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef,
                            uint64_t* ids, float* dist, uint32_t* counts) {
   for (uint32_t b = 0; b < B; ++b) counts[b] = 0;
@@ -582,10 +633,7 @@ int HNSWIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint32_
   if (!has_entry_) return FVDB_OK;  // empty index -> empty results (:404-407)
   if (has_dim_ && dim != dim_) return FVDB_E_DIM;
   if (B == 0 || k == 0) return FVDB_OK;
-  static const bool env_off = getenv("FVDB_HNSW_DEVICE") && atoi(getenv("FVDB_HNSW_DEVICE")) == 0;
-  const uint32_t maxdeg = std::max(cfg_.max_connections, cfg_.max_connections_layer_0);
-  if (!device_traversal_ || env_off || maxdeg + 1 > 64 || ef > 4096)
-    return search_host_walk(q, q_on_device, B, k, ef, ids, dist, counts);
+  if (!device_path_ok(ef)) return search_host_walk(q, q_on_device, B, k, ef, ids, dist, counts);
   const float* qd = q;
   if (!q_on_device) {  // stage the batch in HBM
     const uint64_t bytes = (uint64_t)B * dim * 4;
@@ -600,32 +648,12 @@ int HNSWIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint32_
     if (rc) return rc;
     qd = (const float*)d_q_;
   }
-  std::vector<uint32_t> failed;
-  int rc = search_on_device(qd, B, k, ef, ids, dist, counts, failed);
+  int rc = device_launch(qd, B, k, ef);
   if (rc) return rc;
-  if (!failed.empty()) {  // rare: on-chip heap / visited log overflow -> host walk for those queries
-    n_fallback_ += failed.size();
-    std::vector<float> hq((size_t)failed.size() * dim);
-    for (size_t i = 0; i < failed.size(); ++i) {
-      if (q_on_device) {
-        rc = fvdb_dev_download(ctx_, &hq[i * dim], q + (size_t)failed[i] * dim, (size_t)dim * 4);
-        if (rc) return rc;
-      } else {
-        std::memcpy(&hq[i * dim], q + (size_t)failed[i] * dim, (size_t)dim * 4);
-      }
-    }
-    std::vector<uint64_t> fi(failed.size() * (size_t)k);
-    std::vector<float> fd(failed.size() * (size_t)k);
-    std::vector<uint32_t> fc(failed.size());
-    rc = search_host_walk(hq.data(), false, (uint32_t)failed.size(), k, ef, fi.data(), fd.data(), fc.data());
-    if (rc) return rc;
-    for (size_t i = 0; i < failed.size(); ++i) {
-      std::memcpy(ids + (size_t)failed[i] * k, &fi[i * k], (size_t)k * 8);
-      std::memcpy(dist + (size_t)failed[i] * k, &fd[i * k], (size_t)k * 4);
-      counts[failed[i]] = fc[i];
-    }
-  }
-  return FVDB_OK;
+  std::vector<uint32_t> failed;
+  rc = device_collect(B, k, ids, dist, counts, failed);
+  if (rc) return rc;
+  return finish_failed(q, q_on_device, dim, k, ef, ids, dist, counts, failed);
 }
 
 int HNSWIndex::search_host_walk(const float* q, bool q_on_device, uint32_t B, uint32_t k, uint32_t ef, uint64_t* ids,

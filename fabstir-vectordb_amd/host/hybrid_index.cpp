@@ -55,7 +55,8 @@ int HybridIndex::insert_with_timestamp(uint64_t id, const float* v, uint32_t dim
     int rc = recent_->insert(id, v, dim, level);
     if (rc) return rc;
     recent_count_ += 1;
-    pending_migration_.push_back(id);
+    pending_migration_.push_back({id, ts});
+    pending_min_ts_ = std::min(pending_min_ts_, ts);
   } else {
     int rc = historical_->insert(id, v, dim);
     if (rc) return rc;
@@ -88,7 +89,11 @@ int HybridIndex::bulk_insert(const uint64_t* ids, const float* v, uint64_t n, ui
     int rc = recent_->bulk_build(rid.data(), rv.data(), rid.size(), dim, nullptr);
     if (rc) return rc;
     recent_count_ = rid.size();
-    pending_migration_ = rid;
+    for (uint64_t i = 0; i < n; ++i)
+      if (!ivf_trained_ || age_of(now, ts[i]) < cfg_.recent_threshold_s) {
+        pending_migration_.push_back({ids[i], ts[i]});
+        pending_min_ts_ = std::min(pending_min_ts_, ts[i]);
+      }
   }
   if (!hid.empty()) {
     uint64_t ok = 0;
@@ -138,7 +143,11 @@ int HybridIndex::bulk_insert_sharded(const uint64_t* ids, const float* v, uint64
     int rc = recent_->bulk_build(rid.data(), rv.data(), rid.size(), dim, nullptr);
     if (rc) return rc;
     recent_count_ = rid.size();
-    pending_migration_ = rid;
+    for (uint64_t i = 0; i < n; ++i)
+      if (!ivf_trained_ || age_of(now, ts[i]) < cfg_.recent_threshold_s) {
+        pending_migration_.push_back({ids[i], ts[i]});
+        pending_min_ts_ = std::min(pending_min_ts_, ts[i]);
+      }
   }
   if (!hid.empty()) {
     const uint32_t nlist = historical_->config().n_clusters;
@@ -173,10 +182,20 @@ int HybridIndex::bulk_insert_sharded(const uint64_t* ids, const float* v, uint64
 
 // src/hybrid/core.rs:600-649 — copies into IVF, never removes from HNSW (:577-581)
 uint64_t HybridIndex::migrate_with_threshold(double threshold_s, double now) {
-  if (pending_migration_.empty()) return 0;
-  std::vector<uint64_t> due, keep;
-  for (uint64_t id : pending_migration_) {
-    if (age_of(now, timestamps_[id]) >= threshold_s) due.push_back(id); else keep.push_back(id);
+  // The reference walks the whole timestamps map on every search (:606-617).  Same outcome, O(1) when
+  // nothing is due: only ids still living in HNSW alone can migrate, and none is due while the oldest
+  // of them is younger than the threshold.
+  if (pending_migration_.empty() || age_of(now, pending_min_ts_) < threshold_s) return 0;
+  std::vector<Pending> keep;
+  std::vector<uint64_t> due;
+  double min_ts = 1e300;
+  for (const Pending& p : pending_migration_) {
+    if (age_of(now, p.ts) >= threshold_s) {
+      due.push_back(p.id);
+    } else {
+      keep.push_back(p);
+      min_ts = std::min(min_ts, p.ts);
+    }
   }
   if (due.empty()) return 0;
   uint64_t migrated = 0;
@@ -197,6 +216,7 @@ uint64_t HybridIndex::migrate_with_threshold(double threshold_s, double now) {
   // A copy that failed as a duplicate fails the same way on every later search (the reference
   // retries it each time with no effect), so due ids leave the queue either way.
   pending_migration_.swap(keep);
+  pending_min_ts_ = min_ts;
   if (migrated) {
     recent_count_ = recent_count_ >= migrated ? recent_count_ - migrated : 0;
     historical_count_ += migrated;
@@ -232,14 +252,23 @@ int HybridIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint3
   bool have_r = false, have_h = false;
   static const bool dbg = getenv("FVDB_DEBUG") != nullptr;
   if (dbg) fprintf(stderr, "[hybrid] search B=%u k=%u dev=%d\n", B, k, (int)q_on_device);
-  bool ivf_in_flight = false;
+  bool ivf_in_flight = false, hnsw_in_flight = false;
+  if (cfg.search_recent) {
+    rid.resize((size_t)B * rk);
+    rd.resize((size_t)B * rk);
+    if (q_on_device) {
+      // the graph walk is latency-bound (one wave per query): enqueue it FIRST so that the VALU-bound
+      // list scan launched next fills the rest of every SIMD and the two run concurrently
+      int rcb = 0;
+      hnsw_in_flight = recent_->search_dev_begin(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, &rcb);
+    }
+  }
   if (cfg.search_historical && ivf_trained_) {
     hid.resize((size_t)B * hk);
     hd.resize((size_t)B * hk);
     if (!q_on_device) {
       have_h = historical_->search(q, B, dim, hk, (uint32_t)cfg.ivf_n_probe, hid.data(), hd.data(), hc.data()) == FVDB_OK;
     } else {
-      // enqueue the whole IVF search on its stream; it runs while the host walks the graph below
       const uint64_t need = (uint64_t)B * hk;
       if (need > d_cap_) {
         if (d_hid_) fvdb_dev_free(ctx_ivf_, d_hid_);
@@ -256,12 +285,14 @@ int HybridIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint3
                                               (float*)d_hd_, (uint32_t*)d_hc_) == FVDB_OK;
     }
   }
-  if (dbg) fprintf(stderr, "[hybrid] ivf enqueued (in flight=%d)\n", (int)ivf_in_flight);
+  if (dbg) fprintf(stderr, "[hybrid] enqueued (ivf in flight=%d, hnsw in flight=%d)\n", (int)ivf_in_flight, (int)hnsw_in_flight);
   if (cfg.search_recent) {
-    rid.resize((size_t)B * rk);
-    rd.resize((size_t)B * rk);
-    int rc2 = q_on_device ? recent_->search_dev(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, rid.data(), rd.data(), rc_.data())
-                          : recent_->search(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, rid.data(), rd.data(), rc_.data());
+    int rc2;
+    if (hnsw_in_flight)
+      rc2 = recent_->search_dev_end(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, rid.data(), rd.data(), rc_.data());
+    else
+      rc2 = q_on_device ? recent_->search_dev(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, rid.data(), rd.data(), rc_.data())
+                        : recent_->search(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, rid.data(), rd.data(), rc_.data());
     have_r = rc2 == FVDB_OK;
   }
   if (dbg) fprintf(stderr, "[hybrid] hnsw done\n");
