@@ -185,7 +185,8 @@ struct fvdb_store {
 struct fvdb_graph {
   fvdb_store* store = nullptr;
   uint32_t n = 0, entry = 0, top_level = 0, n_slots = 0;
-  DBuf d_level, d_deleted, d_slot_of, d_slot_start, d_adj;
+  DBuf d_level, d_deleted, d_slot_of, d_slot_start, d_adj, d_adj0;
+  uint32_t stride0 = 0;
   DBuf s_q, s_visited, s_touched;
   uint32_t vis_B = 0, vis_words = 0, vis_tcap = 0;
   bool uploaded = false;
@@ -1340,7 +1341,7 @@ void fvdb_graph_destroy(fvdb_graph* g) {
   if (!g) return;
   (void)hipSetDevice(g->store->ctx->device);
   (void)hipStreamSynchronize(g->store->ctx->stream);
-  DBuf* bufs[] = {&g->d_level, &g->d_deleted, &g->d_slot_of, &g->d_slot_start, &g->d_adj, &g->s_q, &g->s_visited, &g->s_touched};
+  DBuf* bufs[] = {&g->d_level, &g->d_deleted, &g->d_slot_of, &g->d_slot_start, &g->d_adj, &g->d_adj0, &g->s_q, &g->s_visited, &g->s_touched};
   for (DBuf* b : bufs) b->release();
   delete g;
 }
@@ -1360,6 +1361,19 @@ int fvdb_graph_upload(fvdb_graph* g, uint32_t n, const uint32_t* levels, const u
   for (uint32_t sidx = 0; sidx < slots; ++sidx)
     if (slot_start[sidx + 1] - slot_start[sidx] > 64) FAIL(ctx, FVDB_E_UNSUPPORTED, "neighbour list longer than 64");
   const uint32_t edges = slot_start[slots];
+  // layer 0 in fixed-stride form [count, neighbours...]: the walk spends nearly all its hops there
+  uint32_t max0 = 0;
+  for (uint32_t i = 0; i < n; ++i) max0 = std::max(max0, slot_start[slot_of[i] + 1] - slot_start[slot_of[i]]);
+  const uint32_t stride0 = max0 + 1;
+  std::vector<uint32_t> adj0((size_t)n * stride0, 0u);
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t a0 = slot_start[slot_of[i]], c = slot_start[slot_of[i] + 1] - a0;
+    adj0[(size_t)i * stride0] = c;
+    for (uint32_t e = 0; e < c; ++e) adj0[(size_t)i * stride0 + 1 + e] = adj[a0 + e];
+  }
+  HIPCHK(ctx, g->d_adj0.ensure(adj0.size() * 4));
+  HIPCHK(ctx, hipMemcpyAsync(g->d_adj0.p, adj0.data(), adj0.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  g->stride0 = stride0;
   HIPCHK(ctx, g->d_level.ensure((size_t)n * 4));
   HIPCHK(ctx, g->d_deleted.ensure((size_t)n * 4));
   HIPCHK(ctx, g->d_slot_of.ensure((size_t)n * 4));
@@ -1422,7 +1436,22 @@ int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_
   if (lds > 48 * 1024)
     HIPCHK(ctx, hipFuncSetAttribute((const void*)hnsw_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   GraphView gv{s->data, g->d_level.as<uint32_t>(), g->d_deleted.as<uint32_t>(), g->d_slot_of.as<uint32_t>(),
-               g->d_slot_start.as<uint32_t>(), g->d_adj.as<uint32_t>(), g->n, s->dpad, g->entry, g->top_level};
+               g->d_slot_start.as<uint32_t>(), g->d_adj.as<uint32_t>(), g->d_adj0.as<uint32_t>(), g->stride0, g->n,
+               s->dpad, g->entry, g->top_level, nullptr};
+#ifdef FVDB_GRAPH_STAMPS
+  static unsigned long long* d_stamps = nullptr;
+  if (!d_stamps) {
+    (void)hipMalloc(&d_stamps, 64);
+    (void)hipMemset(d_stamps, 0, 64);
+  }
+  gv.stamps = d_stamps;
+  {
+    unsigned long long h[8];
+    (void)hipMemcpy(h, d_stamps, 64, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[graph stamps, cumulative] pop %llu nbr %llu score %llu admit %llu | pending %llu scored-hops %llu hops %llu total %llu\n",
+            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+  }
+#endif
   hipLaunchKernelGGL(hnsw_search_kernel, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
                      g->s_visited.as<uint32_t>(), words, g->s_touched.as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
                      out_counts_dev, out_status_dev);

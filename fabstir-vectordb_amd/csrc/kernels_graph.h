@@ -24,8 +24,19 @@ struct GraphView {
   const uint32_t* slot_of;    // [n] index of the node's layer-0 slot
   const uint32_t* slot_start; // [slots+1] offsets into adj
   const uint32_t* adj;        // neighbour node indices, list order
+  const uint32_t* adj0;       // layer 0 again, fixed stride: adj0[node*stride0] = count, then the neighbours
+  uint32_t stride0;           //   (one dependent load instead of three on the layer that takes ~all hops)
   uint32_t n, dpad, entry, top_level;
+  unsigned long long* stamps;  // diagnostic builds only (FVDB_GRAPH_STAMPS): per-phase cycle sums
 };
+
+#ifdef FVDB_GRAPH_STAMPS
+#define STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define STAMP_ADD(slot, a, b) t_acc[slot] += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, a, b)
+#endif
 
 struct HItem {
   uint32_t node;
@@ -79,6 +90,7 @@ __device__ __forceinline__ HItem h_pop(HItem* h, uint32_t& n) {
 }
 
 constexpr int kTileRows = 16;
+constexpr int kRowsInFlight = 8;
 
 // distances of the wave's query (in LDS) to `np` rows listed in pending[], into pdist[]
 __device__ __forceinline__ void score_pending(const GraphView& g, const float* __restrict__ q_lds, float* tile,
@@ -86,11 +98,16 @@ __device__ __forceinline__ void score_pending(const GraphView& g, const float* _
   const uint32_t dpad = g.dpad, d4 = dpad >> 2, S = dpad + 1;  // odd row stride: lanes hit distinct banks
   for (uint32_t t0 = 0; t0 < np; t0 += kTileRows) {
     const uint32_t rows = min((uint32_t)kTileRows, np - t0);
-    // coalesced row loads (1 KiB per wave-instruction), 4 rows in flight at a time
-    for (uint32_t r0 = 0; r0 < rows; r0 += 4) {
-      float4 v[4][2];
+#ifndef FVDB_GRAPH_REP_LOAD
+#define FVDB_GRAPH_REP_LOAD 1
+#endif
+    // coalesced row loads (1 KiB per wave-instruction), kRowsInFlight rows per round trip
+    for (int repl = 0; repl < FVDB_GRAPH_REP_LOAD; ++repl)
+    for (uint32_t r0 = 0; r0 < rows; r0 += kRowsInFlight) {
+      if (repl) asm volatile("" ::: "memory");
+      float4 v[kRowsInFlight][2];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
+      for (int rr = 0; rr < kRowsInFlight; ++rr) {
         const uint32_t r = r0 + rr;
         if (r < rows) {
           const float4* src = (const float4*)(g.rows + (size_t)pending[t0 + r] * dpad);
@@ -102,7 +119,7 @@ __device__ __forceinline__ void score_pending(const GraphView& g, const float* _
         }
       }
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
+      for (int rr = 0; rr < kRowsInFlight; ++rr) {
         const uint32_t r = r0 + rr;
         if (r < rows) {
 #pragma unroll
@@ -119,7 +136,7 @@ __device__ __forceinline__ void score_pending(const GraphView& g, const float* _
         }
       }
       for (uint32_t c = 128 + lane; c < d4; c += 64) {  // d > 512: remaining chunks, row by row
-        for (uint32_t r = r0; r < min(r0 + 4, rows); ++r) {
+        for (uint32_t r = r0; r < min(r0 + (uint32_t)kRowsInFlight, rows); ++r) {
           const float4 w = ((const float4*)(g.rows + (size_t)pending[t0 + r] * dpad))[c];
           float* dst = tile + r * S + 4 * c;
           dst[0] = w.x;
@@ -131,12 +148,37 @@ __device__ __forceinline__ void score_pending(const GraphView& g, const float* _
     }
     __builtin_amdgcn_s_waitcnt(0);  // the wave's LDS writes land before its reads
     __builtin_amdgcn_wave_barrier();
+#ifndef FVDB_GRAPH_REP_DIST
+#define FVDB_GRAPH_REP_DIST 1
+#endif
+    for (int rep = 0; rep < FVDB_GRAPH_REP_DIST; ++rep)
     if ((uint32_t)lane < rows) {  // one lane per row: the reference's left-to-right f32 fold
       const float* x = tile + lane * S;
       float acc = 0.0f;
-#pragma unroll 8
-      for (uint32_t j = 0; j < dpad; j += 4) {
-        const float4 qv = *(const float4*)(q_lds + j);  // same address in every lane: LDS broadcast
+      if (rep) asm volatile("" ::: "memory");
+      uint32_t j = 0;
+      // 32 dims per step: all LDS reads of a step are issued before its arithmetic starts (a lone wave
+      // per SIMD has nothing else to hide the ~100-cycle LDS latency behind)
+      for (; j + 32 <= dpad; j += 32) {
+        float xv[32];
+        float4 qv[8];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) xv[i] = x[j + i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qv[i] = *(const float4*)(q_lds + j + 4 * i);  // LDS broadcast
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float t;
+          t = qv[i].x - xv[4 * i + 0]; acc = acc + t * t;
+          t = qv[i].y - xv[4 * i + 1]; acc = acc + t * t;
+          t = qv[i].z - xv[4 * i + 2]; acc = acc + t * t;
+          t = qv[i].w - xv[4 * i + 3]; acc = acc + t * t;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      for (; j < dpad; j += 4) {
+        const float4 qv = *(const float4*)(q_lds + j);
         float t;
         t = qv.x - x[j + 0]; acc = acc + t * t;
         t = qv.y - x[j + 1]; acc = acc + t * t;
@@ -159,7 +201,7 @@ __host__ __device__ inline size_t graph_lds_bytes(uint32_t dpad, uint32_t ef, ui
   return (b + 15) & ~(size_t)15;
 }
 
-__global__ __launch_bounds__(64) void hnsw_search_kernel(const GraphView g, const float* __restrict__ queries,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void hnsw_search_kernel(const GraphView g, const float* __restrict__ queries,
                                                          uint32_t B, uint32_t k, uint32_t ef_final, uint32_t cand_cap,
                                                          uint32_t* __restrict__ visited /* [B][words] zero on entry */,
                                                          uint32_t words, uint32_t* __restrict__ touched /* [B][tcap] */,
@@ -198,6 +240,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const GraphView g, cons
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
 
+#ifdef FVDB_GRAPH_STAMPS
+  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
   for (uint32_t layer = g.top_level + 1; layer-- > 0;) {
     const uint32_t ef = layer == 0 ? ef_final : 1;
     uint32_t nC = 0, nN = 0, nT = 0;  // lane 0's copies are authoritative
@@ -212,6 +258,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const GraphView g, cons
     }
     nT = 1;
     for (;;) {
+      STAMP(t0s);
       if (lane == 0) {
         uint32_t stop = 0, node = 0;
         if (nC == 0) {
@@ -228,14 +275,24 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const GraphView g, cons
       __builtin_amdgcn_wave_barrier();
       const uint32_t stop = sc[0], node = sc[1];
       if (stop) break;
+      STAMP(t1s);
+      STAMP_ADD(0, t0s, t1s);
       uint32_t np = 0;
-      if (g.level[node] >= layer) {
-        const uint32_t s = g.slot_of[node] + layer;
-        const uint32_t a0 = g.slot_start[s], cnt = g.slot_start[s + 1] - a0;  // cnt <= 64 (host checks the degree cap)
-        uint32_t nb = 0;
+      if (layer == 0 || g.level[node] >= layer) {
+        uint32_t cnt, nb = 0;
+        if (layer == 0) {  // count and neighbours arrive with one load
+          const uint32_t* row = g.adj0 + (size_t)node * g.stride0;
+          const uint32_t w = (uint32_t)lane < g.stride0 ? row[lane] : 0u;
+          cnt = __builtin_amdgcn_readfirstlane(w);
+          nb = __shfl_down(w, 1);  // lane i holds neighbour i
+        } else {
+          const uint32_t s = g.slot_of[node] + layer;
+          const uint32_t a0 = g.slot_start[s];
+          cnt = g.slot_start[s + 1] - a0;  // cnt <= 64 (host checks the degree cap)
+          if ((uint32_t)lane < cnt) nb = g.adj[a0 + lane];
+        }
         bool fresh = false, keep = false;
         if ((uint32_t)lane < cnt) {
-          nb = g.adj[a0 + lane];
           const uint32_t bit = 1u << (nb & 31);
           fresh = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;  // visited.insert (:506-507)
           keep = fresh && g.deleted[nb] == 0;                  // :511-513
@@ -255,8 +312,16 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const GraphView g, cons
       if (overflow) break;
       __builtin_amdgcn_s_waitcnt(0);
       __builtin_amdgcn_wave_barrier();
+      STAMP(t2s);
+      STAMP_ADD(1, t1s, t2s);
       if (np) {
         score_pending(g, q_lds, tile, pending, pdist, np, lane);
+        STAMP(t3s);
+        STAMP_ADD(2, t2s, t3s);
+#ifdef FVDB_GRAPH_STAMPS
+        t_acc[4] += np;
+        t_acc[5] += 1;
+#endif
         if (lane == 0) {
           for (uint32_t i = 0; i < np; ++i) {  // admission rule :517-531, neighbour order
             const float d = pdist[i];
@@ -273,11 +338,16 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const GraphView g, cons
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
+        STAMP(t4s);
+        STAMP_ADD(3, t3s, t4s);
         if (sc[2]) {
           overflow = true;
           break;
         }
       }
+#ifdef FVDB_GRAPH_STAMPS
+      t_acc[6] += 1;
+#endif
     }
     // ---- result of the layer: nearest in heap order, stable-sorted by distance (:541-553) ----
     if (lane == 0) sc[3] = nN;
@@ -316,6 +386,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const GraphView g, cons
       return;
     }
   }
+#ifdef FVDB_GRAPH_STAMPS
+  if (lane == 0 && g.stamps) {
+    t_acc[7] = __builtin_amdgcn_s_memtime() - t_begin;
+    for (int i = 0; i < 8; ++i) atomicAdd(g.stamps + i, t_acc[i]);
+  }
+#endif
   // ---- filter deleted, take k (:451-466) ----
   if (lane == 0) {
     uint32_t w = 0;
