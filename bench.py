@@ -99,6 +99,10 @@ def main():
     ap.add_argument("--query-batches", type=int, default=4)
     ap.add_argument("--cpu-sample", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hnsw-traversal", choices=["device", "host"], default="device",
+                    help="device: the layered walk runs on the GPU (one launch per batch); host: on the host with one "
+                         "candidate-scoring launch per hop (the north_star's split).  Identical results.")
+    ap.add_argument("--compare-host-walk", type=int, default=5, help="extra steps timed with the host walk (0 = skip)")
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--spread", type=float, default=1.5)
     args = ap.parse_args()
@@ -170,6 +174,7 @@ def main():
     log(f"exact ground truth: {time.time() - t0:.1f}s")
 
     qdev = [ctx_ivf.upload(q) for q in queries]
+    hyb.hnsw().set_device_traversal(args.hnsw_traversal == "device")
 
     def run(i, nprobe, ef):
         if sharded is not None:
@@ -235,6 +240,22 @@ def main():
     stats = hyb.ivf_device_last_stats()
     evals, hops = hnsw.dist_evals() - evals0, hnsw.hops() - hops0
 
+    # the same workload with the other traversal mode (reported next to the headline value)
+    other = None
+    if args.compare_host_walk > 0 and world == 1:
+        hnsw.set_device_traversal(args.hnsw_traversal != "device")
+        run(0, nprobe, ef)
+        ctx_ivf.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.compare_host_walk):
+            run(i, nprobe, ef)
+        ctx_ivf.synchronize()
+        dt = (time.perf_counter() - t1) / args.compare_host_walk
+        other = {"hnsw_traversal": "host" if args.hnsw_traversal == "device" else "device",
+                 "value": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "steps": args.compare_host_walk}
+        hnsw.set_device_traversal(args.hnsw_traversal == "device")
+        log(f"other traversal mode ({other['hnsw_traversal']}): {other['ms_per_step']} ms/step, {other['value']:.0f} QPS")
+
     recs = []
     for i in range(nb):
         res = run(i, nprobe, ef)
@@ -251,7 +272,7 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
         "frac": round(achieved / 8000.0, 4), "traffic": None,
-        "kernel": "scan_topk_kernel<16,1> (IVF list scan)", "kernel_ms": round(scan_ms, 4),
+        "kernel": "fvdb::scan_topk_kernel<16, 1, 1> (IVF list scan)", "kernel_ms": round(scan_ms, 4),
         "algorithmic_bytes_per_launch": int(alg_bytes),
         "rows_scanned_per_query": round(stats["rows_scanned"] / B, 1),
         "physical_lower_bound_bytes_per_launch": int(stats["list_rows_touched"] * d * 4),
@@ -278,7 +299,8 @@ def main():
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "c3: 1M x 384 f32 hybrid HNSW/IVF (10K-vector chunks), batch 1024, k 10",
                        "n_vectors": N, "dim": d, "batch": B, "k": k, "recent_frac_hnsw": args.recent_frac,
-                       "nlist": args.nlist, "nprobe": nprobe, "hnsw_ef": ef, "hnsw_M": 16, "hnsw_M0": 32,
+                       "nlist": args.nlist, "nprobe": nprobe, "hnsw_ef": ef, "hnsw_M": 16, "hnsw_M0": 32, "hnsw_traversal": args.hnsw_traversal,
+                       "other_traversal_mode": other, "hnsw_device_fallbacks": hnsw.device_fallbacks(),
                        "recall_at_10": round(recall, 4), "recall_target": args.recall_target, "sweep": sweep,
                        "generator": f"gaussian mixture: 4096 comps, means {args.spread}*N(0,I) in a rank-{args.latent} latent space, "
                                     f"unit within-comp sigma, orthonormal embedding into {d}-d + 0.02 ambient noise",
