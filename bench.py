@@ -285,6 +285,17 @@ def main():
         "hnsw": {"hops_per_step": round(hops / args.steps, 1), "dist_evals_per_query": round(evals / args.steps / B, 1)},
     }
 
+    # HBM-side traffic of that kernel from PMC counters (FETCH_SIZE / WRITE_SIZE are collected in their own
+    # rocprofv3 passes by tools/pmc_traffic.sh for this same command and committed under profiles/;
+    # gfx950: FETCH_SIZE counts wide streaming reads at half their bytes => doubled, see MI355X_MICROARCH.md)
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["list_scan"]
+        if N == 1_000_000 and nprobe == 48 and world == 1:
+            roofline["traffic"] = int((2 * pm["FETCH_SIZE_KB_avg"] + pm["WRITE_SIZE_KB_avg"]) * 1024)
+            roofline["traffic_note"] = "bytes per launch beyond L2 (Infinity Cache + HBM), 2*FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json"
+    except Exception:
+        pass
+
     # ---- CPU baseline: the oracle (reference algorithm restated) on the same structures ----
     cpu = None
     if not args.no_cpu_baseline and rank == 0:
