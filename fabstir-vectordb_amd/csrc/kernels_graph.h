@@ -322,10 +322,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         t_acc[4] += np;
         t_acc[5] += 1;
 #endif
+        // Admission rule (:517-531) in neighbour order.  Once `nearest` is full its worst distance only
+        // shrinks while the neighbours are applied, so a candidate that fails against the worst as it
+        // stands now can never be admitted later in this hop: all lanes test that at once and lane 0
+        // walks only the survivors (in order, re-testing against the current worst).
+        const uint32_t nN0 = __builtin_amdgcn_readfirstlane(nN);
+        const float worst0 = -near[0].d;
+        const bool maybe = (uint32_t)lane < np && (nN0 < ef || pdist[lane] < worst0);
+        uint64_t todo = __ballot(maybe);
         if (lane == 0) {
-          for (uint32_t i = 0; i < np; ++i) {  // admission rule :517-531, neighbour order
+          float worst = worst0;
+          while (todo) {
+            const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
             const float d = pdist[i];
-            if (d < -near[0].d || nN < ef) {
+            if (d < worst || nN < ef) {
               if (nC >= cand_cap) {
                 sc[2] = 1;
                 break;
@@ -333,6 +344,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
               h_push(cand, nC, HItem{pending[i], d});
               h_push(near, nN, HItem{pending[i], -d});
               if (nN > ef) (void)h_pop(near, nN);
+              worst = -near[0].d;
             }
           }
         }
