@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--n-vectors", dest="n", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
@@ -116,10 +116,12 @@ def main():
         args.gpus = world
     dist = None
     torch = None
-    if world > 1:
+    force_sharded = os.environ.get("FVDB_FORCE_SHARDED") == "1"  # exercise the multi-GPU code path on one rank
+    if world > 1 or force_sharded:
         import torch  # noqa: F811  (first, so this process uses one HIP runtime)
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
@@ -154,7 +156,7 @@ def main():
     # ---- placement: single GPU = everything; multi GPU = lists sharded, HNSW replicated ----
     t0 = time.time()
     sharded = None
-    if world == 1:
+    if world == 1 and not force_sharded:
         hyb.bulk_insert(ids, x, ts, now)
     else:
         from fabstir_vectordb_amd import sharded as sh
@@ -348,7 +350,7 @@ def cpu_baseline(fv, hyb, sharded, x, ids, is_recent, ts, now, q0, gpu_res, k, n
     oi, od, oc = o.batch_search(q0[:ns], k, now=now, hnsw_ef=ef, ivf_n_probe=nprobe, threads=threads)
     tall = time.perf_counter() - t0
     same = bool(np.array_equal(oc, gpu_res.counts[:ns]) and np.array_equal(oi, gpu_res.ids[:ns]) and
-                np.array_equal(od.view(np.uint32), gpu_res.distances[:ns].view(np.uint32))) if sharded is None else None
+                np.array_equal(od.view(np.uint32), gpu_res.distances[:ns].view(np.uint32)))
     log(f"cpu baseline: setup {setup_s:.1f}s; 1 thread {max(8, ns // 8) / t1:.1f} q/s; {threads} threads {ns / tall:.1f} q/s; "
         f"gpu==oracle on the sample: {same}")
     return {"value": round(ns / tall, 2), "unit": "queries/s", "cores": threads, "kind": "port",
