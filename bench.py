@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--ef", type=int, default=0, help="0 = smallest of the sweep reaching the recall target")
     ap.add_argument("--recent-frac", type=float, default=0.3)
     ap.add_argument("--recall-target", type=float, default=0.95)
-    ap.add_argument("--train-sample", type=int, default=50_000)
+    ap.add_argument("--train-sample", type=int, default=100_000)
     ap.add_argument("--query-batches", type=int, default=4)
     ap.add_argument("--cpu-sample", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")

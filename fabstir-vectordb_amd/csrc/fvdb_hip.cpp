@@ -997,7 +997,7 @@ int fvdb_ivf_train(fvdb_ivf* ivf, const float* x, uint64_t n, uint32_t max_itera
     hipLaunchKernelGGL(kpp_min_dist_kernel, dim3(gn), dim3(256), 0, ctx->stream, dx.as<float>(), d, n, pick,
                        dmind.as<float>());
     const float u = (float)(rng.next() >> 40) * (1.0f / 16777216.0f);
-    hipLaunchKernelGGL(kpp_pick_kernel, dim3(1), dim3(64), 0, ctx->stream, dmind.as<float>(), n, u,
+    hipLaunchKernelGGL(kpp_pick_kernel, dim3(1), dim3(256), 0, ctx->stream, dmind.as<float>(), n, u,
                        (unsigned long long*)dsc.p);
     unsigned long long p = 0;
     TCHK(hipMemcpyAsync(&p, dsc.p, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1016,7 +1016,7 @@ int fvdb_ivf_train(fvdb_ivf* ivf, const float* x, uint64_t n, uint32_t max_itera
   auto error_of = [&](float* out_err) -> int {
     hipLaunchKernelGGL(kmeans_point_dist_kernel, dim3(gn), dim3(256), 0, ctx->stream, dx.as<float>(), d, n,
                        dassign.as<uint32_t>(), cent, ddist.as<float>());
-    hipLaunchKernelGGL(seq_sqsum_mean_kernel, dim3(1), dim3(64), 0, ctx->stream, ddist.as<float>(), n,
+    hipLaunchKernelGGL(seq_sqsum_mean_kernel, dim3(1), dim3(256), 0, ctx->stream, ddist.as<float>(), n,
                        (float*)dsc.p + 4);
     float r[2];
     HIPCHK(ctx, hipMemcpyAsync(r, (float*)dsc.p + 4, 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -136,11 +136,24 @@ __global__ void kmeans_point_dist_kernel(const float* __restrict__ x, uint32_t d
   dist[i] = sqrtf(acc);
 }
 
-// total = sum_i dist_i*dist_i in index order (one lane; n adds), out = total / n
-__global__ void seq_sqsum_mean_kernel(const float* __restrict__ dist, uint64_t n, float* __restrict__ out) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float total = 0.0f;
-    for (uint64_t i = 0; i < n; ++i) total += dist[i] * dist[i];
+// Sequential f32 sums in index order (the reference's folds) without paying a global-memory latency per
+// element: the block stages 8K-element tiles in LDS with coalesced loads, thread 0 folds each tile.
+constexpr int kSeqTile = 8192;
+
+// total = sum_i dist_i*dist_i in index order, out[0] = total / n, out[1] = total   (src/ivf/core.rs:419-429)
+__global__ __launch_bounds__(256) void seq_sqsum_mean_kernel(const float* __restrict__ dist, uint64_t n,
+                                                             float* __restrict__ out) {
+  __shared__ float tile[kSeqTile];
+  float total = 0.0f;
+  for (uint64_t base = 0; base < n; base += kSeqTile) {
+    const uint32_t m = (uint32_t)min((uint64_t)kSeqTile, n - base);
+    for (uint32_t i = threadIdx.x; i < m; i += 256) tile[i] = dist[base + i];
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (uint32_t i = 0; i < m; ++i) total += tile[i] * tile[i];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
     out[0] = total / (float)n;
     out[1] = total;
   }
@@ -161,23 +174,45 @@ __global__ void kpp_min_dist_kernel(const float* __restrict__ x, uint32_t d, uin
   }
   mind[i] = fminf(mind[i], sqrtf(acc));
 }
-// sequential: total = sum d^2; threshold = u * total; first j with cumulative >= threshold
-__global__ void kpp_pick_kernel(const float* __restrict__ mind, uint64_t n, float u, unsigned long long* out_pick) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float total = 0.0f;
-    for (uint64_t j = 0; j < n; ++j) total += mind[j] * mind[j];
-    const float threshold = u * total;
-    float cumulative = 0.0f;
-    unsigned long long pick = ~0ull;
-    for (uint64_t j = 0; j < n; ++j) {
-      cumulative += mind[j] * mind[j];
-      if (cumulative >= threshold) {
-        pick = j;
-        break;
+// sequential: total = sum d^2; threshold = u * total; first j with cumulative >= threshold (:357-367)
+__global__ __launch_bounds__(256) void kpp_pick_kernel(const float* __restrict__ mind, uint64_t n, float u,
+                                                       unsigned long long* out_pick) {
+  __shared__ float tile[kSeqTile];
+  __shared__ float s_threshold;
+  __shared__ unsigned long long s_pick;
+  float total = 0.0f;
+  for (uint64_t base = 0; base < n; base += kSeqTile) {
+    const uint32_t m = (uint32_t)min((uint64_t)kSeqTile, n - base);
+    for (uint32_t i = threadIdx.x; i < m; i += 256) tile[i] = mind[base + i];
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (uint32_t i = 0; i < m; ++i) total += tile[i] * tile[i];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    s_threshold = u * total;
+    s_pick = ~0ull;
+  }
+  __syncthreads();
+  float cumulative = 0.0f;
+  for (uint64_t base = 0; base < n; base += kSeqTile) {
+    if (s_pick != ~0ull) break;  // uniform: written before the barrier below
+    const uint32_t m = (uint32_t)min((uint64_t)kSeqTile, n - base);
+    for (uint32_t i = threadIdx.x; i < m; i += 256) tile[i] = mind[base + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float threshold = s_threshold;
+      for (uint32_t i = 0; i < m; ++i) {
+        cumulative += tile[i] * tile[i];
+        if (cumulative >= threshold) {
+          s_pick = base + i;
+          break;
+        }
       }
     }
-    *out_pick = pick;
+    __syncthreads();
   }
+  if (threadIdx.x == 0) *out_pick = s_pick;
 }
 __global__ void fill_f32_kernel(float* p, uint64_t n, float v) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,248 @@
+"""VectorDbSession / REST search surface over the GPU hybrid index.
+
+Mirrors the observable behaviour of the reference's two public surfaces for the hot path:
+  * Node binding  bindings/node/src/session.rs  (search :203-336, add_vectors :340-432, delete)
+  * REST handler  src/api/rest.rs               (search :599-677)
+Kept: f64 -> f32 narrowing of inputs (bindings/node/src/utils.rs:6-8), dimension latch and mismatch
+errors, first-call initialisation with the first <= 10 vectors (session.rs:365-378), score =
+1/(1+distance) computed in f32 (session.rs:291,328; rest.rs:653), default threshold 0.0, results in
+ascending distance, `_originalId` round trip, ids shown as `vec_<8 hex of BLAKE3>` when no original id
+exists (src/core/types.rs:32-34).  Not built (out of scope): persistence, schema
+validation, metadata filters, native metadata types.
+
+`blake3()` below is written from the published BLAKE3 specification (the `blake3` crate is not
+available here); it is pinned by the official known-answer vector for the empty input.
+"""
+import struct
+
+import numpy as np
+
+from .index import HybridIndex
+
+# ---------------------------------------------------------------------------------------------
+# BLAKE3 (hash mode, 32-byte output) — VectorId::from_string (src/core/types.rs:19-22)
+# ---------------------------------------------------------------------------------------------
+_IV = (0x6A09E667, 0xBB67AE85, 0x3C6EF372, 0xA54FF53A, 0x510E527F, 0x9B05688C, 0x1F83D9AB, 0x5BE0CD19)
+_PERM = (2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8)
+_CHUNK_START, _CHUNK_END, _PARENT, _ROOT = 1, 2, 4, 8
+_M32 = 0xFFFFFFFF
+
+
+def _rotr(x, n):
+    return ((x >> n) | (x << (32 - n))) & _M32
+
+
+def _g(s, a, b, c, d, mx, my):
+    s[a] = (s[a] + s[b] + mx) & _M32
+    s[d] = _rotr(s[d] ^ s[a], 16)
+    s[c] = (s[c] + s[d]) & _M32
+    s[b] = _rotr(s[b] ^ s[c], 12)
+    s[a] = (s[a] + s[b] + my) & _M32
+    s[d] = _rotr(s[d] ^ s[a], 8)
+    s[c] = (s[c] + s[d]) & _M32
+    s[b] = _rotr(s[b] ^ s[c], 7)
+
+
+def _compress(cv, block_words, counter, block_len, flags):
+    s = list(cv) + list(_IV[:4]) + [counter & _M32, (counter >> 32) & _M32, block_len, flags]
+    m = list(block_words)
+    for r in range(7):
+        _g(s, 0, 4, 8, 12, m[0], m[1])
+        _g(s, 1, 5, 9, 13, m[2], m[3])
+        _g(s, 2, 6, 10, 14, m[4], m[5])
+        _g(s, 3, 7, 11, 15, m[6], m[7])
+        _g(s, 0, 5, 10, 15, m[8], m[9])
+        _g(s, 1, 6, 11, 12, m[10], m[11])
+        _g(s, 2, 7, 8, 13, m[12], m[13])
+        _g(s, 3, 4, 9, 14, m[14], m[15])
+        if r < 6:
+            m = [m[p] for p in _PERM]
+    for i in range(8):
+        s[i] ^= s[i + 8]
+        s[i + 8] ^= cv[i]
+    return s
+
+
+def _words(block):
+    return struct.unpack("<16I", block.ljust(64, b"\0"))
+
+
+def _chunk_output(chunk, counter):
+    """(cv, last block words, last block len, flags-without-ROOT) of one <=1024-byte chunk."""
+    cv = _IV
+    blocks = [chunk[i:i + 64] for i in range(0, len(chunk), 64)] or [b""]
+    for i, blk in enumerate(blocks[:-1]):
+        flags = _CHUNK_START if i == 0 else 0
+        cv = tuple(_compress(cv, _words(blk), counter, 64, flags)[:8])
+    last = blocks[-1]
+    flags = (_CHUNK_START if len(blocks) == 1 else 0) | _CHUNK_END
+    return cv, _words(last), len(last), flags, counter
+
+
+def blake3(data: bytes) -> bytes:
+    chunks = [data[i:i + 1024] for i in range(0, len(data), 1024)] or [b""]
+    if len(chunks) == 1:
+        cv, w, blen, flags, ctr = _chunk_output(chunks[0], 0)
+        out = _compress(cv, w, ctr, blen, flags | _ROOT)
+        return struct.pack("<8I", *out[:8])
+    # binary tree over chunk chaining values: left subtrees are the largest power of two
+    def subtree_cv(lo, hi):
+        if hi - lo == 1:
+            cv, w, blen, flags, ctr = _chunk_output(chunks[lo], lo)
+            return tuple(_compress(cv, w, ctr, blen, flags)[:8])
+        n = hi - lo
+        left = 1 << ((n - 1).bit_length() - 1)
+        l, r = subtree_cv(lo, lo + left), subtree_cv(lo + left, hi)
+        return tuple(_compress(_IV, l + r, 0, 64, _PARENT)[:8])
+
+    n = len(chunks)
+    left = 1 << ((n - 1).bit_length() - 1)
+    l, r = subtree_cv(0, left), subtree_cv(left, n)
+    out = _compress(_IV, l + r, 0, 64, _PARENT | _ROOT)
+    return struct.pack("<8I", *out[:8])
+
+
+class VectorId:
+    """32-byte BLAKE3 of the string id (src/core/types.rs:9-43)."""
+
+    def __init__(self, s):
+        self.bytes = blake3(s.encode("utf-8"))
+
+    def to_string(self):
+        return "vec_" + self.bytes[:4].hex()  # `vec_<8 hex>` (src/core/types.rs:32-34)
+
+    def row_id(self):
+        return struct.unpack("<Q", self.bytes[:8])[0]  # u64 row id handed to the engine
+
+
+def js_array_to_vec_f32(v):
+    """bindings/node/src/utils.rs:6-8: `x as f32` per element (round to nearest even)."""
+    return np.asarray(v, dtype=np.float64).astype(np.float32)
+
+
+class SessionError(Exception):
+    pass
+
+
+class VectorDbSession:
+    """bindings/node/src/session.rs VectorDBSession — search()/addVectors()/deleteVector() on the GPU index."""
+
+    def __init__(self, ctx, now=0.0, **hybrid_config):
+        self.ctx = ctx
+        self.index = HybridIndex(ctx, **hybrid_config)   # HybridConfig::default unless overridden
+        self.vector_dimension = None                        # latched by the first addVectors (:345-357)
+        self.metadata = {}                                  # VectorId string -> metadata (with _originalId)
+        self._rows = {}                                     # u64 row id -> VectorId string
+        self.now = now
+        self.destroyed = False
+
+    # -- add_vectors: session.rs:340-432 -------------------------------------------------------
+    def add_vectors(self, vectors):
+        """vectors: iterable of dicts {"id": str, "vector": [float], "metadata": any}."""
+        if self.destroyed:
+            raise SessionError("Session already destroyed")
+        vectors = list(vectors)
+        if vectors:
+            first_dim = len(vectors[0]["vector"])
+            if self.vector_dimension is not None and first_dim != self.vector_dimension:
+                raise SessionError(f"Vector dimension mismatch: expected {self.vector_dimension}, got {first_dim}")
+            if self.vector_dimension is None:
+                self.vector_dimension = first_dim
+        if not self.index.is_initialized() and vectors:
+            training = np.stack([js_array_to_vec_f32(v["vector"]) for v in vectors[:10]])  # first 10 (:367-371)
+            self.index.initialize(training)
+        for inp in vectors:
+            vid = VectorId(inp["id"])
+            vec = js_array_to_vec_f32(inp["vector"])
+            if vec.size != self.vector_dimension:
+                raise SessionError(f"Vector dimension mismatch: expected {self.vector_dimension}, got {vec.size}")
+            try:
+                self.index.insert(vid.row_id(), vec, now=self.now)
+            except Exception as e:  # index errors surface as strings (bindings/node/src/error.rs:61-65)
+                raise SessionError(f"Failed to add vector: {e}") from e
+            md = inp.get("metadata", {})
+            if isinstance(md, dict):
+                md = dict(md)
+                md["_originalId"] = inp["id"]
+            else:
+                md = {"_originalId": inp["id"], "_userMetadata": md}
+            self.metadata[vid.to_string()] = md
+            self._rows[vid.row_id()] = vid.to_string()
+
+    addVectors = add_vectors
+
+    # -- search: session.rs:203-336 ------------------------------------------------------------------
+    def search(self, query_vector, k, options=None):
+        if self.destroyed:
+            raise SessionError("Session already destroyed")
+        options = options or {}
+        q = js_array_to_vec_f32(query_vector)
+        if self.vector_dimension is not None and q.size != self.vector_dimension:
+            raise SessionError(
+                f"Query vector dimension mismatch: expected {self.vector_dimension} dimensions, got {q.size}")
+        threshold = np.float32(options.get("threshold", 0.0))
+        if options.get("filter") is not None:
+            raise SessionError("metadata filters are outside the accelerated path (SURVEY.md section 2, row 15)")
+        try:
+            res = self.index.search(q.reshape(1, -1), int(k), now=self.now)  # HybridIndex::search defaults (ef 50, nprobe 10)
+        except Exception as e:
+            raise SessionError(f"Search failed: {e}") from e
+        out = []
+        ids, ds = res[0]
+        for rid, d in zip(ids.tolist(), ds.tolist()):
+            score = np.float32(1.0) / (np.float32(1.0) + np.float32(d))
+            if not score >= threshold:
+                continue
+            key = self._rows.get(rid, f"row_{rid}")
+            md = dict(self.metadata.get(key, {}))
+            rid_out = key
+            if isinstance(md.get("_originalId"), str):
+                rid_out = md.pop("_originalId")
+                if "_userMetadata" in md:
+                    md = md.pop("_userMetadata")
+            out.append({"id": rid_out, "score": float(score), "metadata": md})
+        return out
+
+    def delete_vector(self, id):
+        vid = VectorId(id)
+        try:
+            self.index.delete(vid.row_id(), self.now)
+        except Exception as e:
+            raise SessionError(f"Failed to delete vector: {e}") from e
+
+    deleteVector = delete_vector
+
+    def get_stats(self):
+        return {"vector_count": self.index.recent_count() + self.index.historical_count(),
+                "hnsw_vector_count": self.index.recent_count(), "ivf_vector_count": self.index.historical_count()}
+
+    def destroy(self):
+        self.destroyed = True
+        self.index = None
+
+
+def rest_search(index, request, id_of_row=None, now=0.0):
+    """POST /api/v1/search (src/api/rest.rs:599-677) for one request dict {"vector": [...], "k": int,
+    "options": {...}}.  Like the handler, the hybrid search runs with the default config (the handler builds a
+    HybridSearchConfig but calls `hybrid_index.search(&vector, k)`, :631-634)."""
+    import time
+    vec = np.asarray(request["vector"], dtype=np.float32)
+    if vec.size == 0 or not np.all(np.isfinite(vec)):
+        raise ValueError("Invalid vector")  # validate_vector -> 400
+    k = int(request["k"])
+    opts = request.get("options") or {}
+    t0 = time.perf_counter()
+    res = index.search(vec.reshape(1, -1), k, now=now)
+    ids, ds = res[0]
+    results = []
+    for rid, d in zip(ids.tolist(), ds.tolist()):
+        score = float(np.float32(1.0) / (np.float32(1.0) + np.float32(d)))
+        item = {"id": id_of_row(rid) if id_of_row else f"row_{rid}", "distance": float(np.float32(d)), "score": score}
+        if opts.get("include_metadata", False):
+            item["metadata"] = {}
+        results.append(item)
+    if opts.get("score_threshold") is not None:
+        results = [r for r in results if r["score"] >= opts["score_threshold"]]
+    sr, sh = opts.get("search_recent", True), opts.get("search_historical", True)
+    return {"results": results, "search_time_ms": (time.perf_counter() - t0) * 1e3,
+            "indices_searched": 2 if (sr and sh) else 1, "partial_results": False}

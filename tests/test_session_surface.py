@@ -1,0 +1,70 @@
+"""Session / REST surface above the seam (bindings/node/src/session.rs, src/api/rest.rs) and the
+from-spec BLAKE3 behind VectorId (src/core/types.rs:9-43)."""
+import numpy as np
+import pytest
+
+import fvdb_import
+
+fv = fvdb_import.load()
+
+
+def _inp(n):
+    return bytes(i % 251 for i in range(n))
+
+
+def test_blake3_known_answers():
+    # official BLAKE3 test vectors (test_vectors.json: input byte i = i % 251), first 32 output bytes
+    assert fv.blake3(b"").hex() == "af1349b9f5f9a1a6a0404dea36dcc9499bcb25c9adc112b7cc9a93cae41f3262"
+    assert fv.blake3(_inp(1)).hex() == "2d3adedff11b61f14c886e35afa036736dcd87a74d27b5c1510225d0f592e213"
+    assert fv.blake3(_inp(1024)).hex().startswith("42214739f095a406")   # exactly one chunk
+    assert fv.blake3(_inp(1025)).hex().startswith("d00278ae47eb27b3")   # two chunks -> parent node
+    assert fv.blake3(_inp(2049)).hex().startswith("5f4d72f40d7a5f82")   # three chunks, unbalanced tree
+
+
+def test_vector_id_display_form():
+    a, b = fv.VectorId("a"), fv.VectorId("b")
+    assert a.to_string().startswith("vec_") and len(a.to_string()) == 12  # `vec_<8 hex>` src/core/types.rs:32-34
+    assert a.to_string() != b.to_string() and a.row_id() != b.row_id()
+    assert fv.VectorId("a").bytes == a.bytes
+
+
+def test_js_array_narrowing_is_round_to_nearest_f32():
+    # bindings/node/src/utils.rs:6-8 `v as f32`
+    v = fv.session.js_array_to_vec_f32([0.1, 1.0 + 2.0**-30, 16777217.0])
+    assert v.dtype == np.float32 and v[0] == np.float32(0.1) and v[1] == np.float32(1.0) and v[2] == np.float32(16777216.0)
+
+
+@pytest.mark.gpu
+def test_session_topk_and_scores():
+    # bindings/node/test/test-topk-bug.js:25-83 (k=3/10/100 on 20 vectors -> 3/10/20 hits),
+    # bindings/node/test/session.test.js:161-163 (score in [0,1]), _originalId round trip
+    ctx = fv.Context(0)
+    s = fv.VectorDbSession(ctx)
+    s.add_vectors([{"id": f"doc-{i}", "vector": [float(i), 1.0, 0.5], "metadata": {"n": i}} for i in range(20)])
+    assert s.get_stats()["vector_count"] == 20
+    for k, want in ((3, 3), (10, 10), (100, 20)):
+        assert len(s.search([0.0, 1.0, 0.5], k)) == want
+    res = s.search([0.0, 1.0, 0.5], 5)
+    assert res[0]["id"] == "doc-0" and res[0]["score"] == 1.0 and res[0]["metadata"] == {"n": 0}
+    assert all(0.0 <= r["score"] <= 1.0 for r in res)
+    assert [r["score"] for r in res] == sorted((r["score"] for r in res), reverse=True)
+    d1 = np.float32(1.0)  # doc-1 is at distance 1 -> score 1/(1+1) in f32
+    assert res[1]["score"] == float(np.float32(1.0) / (np.float32(1.0) + d1))
+    assert len(s.search([0.0, 1.0, 0.5], 20, {"threshold": 0.3})) == 3  # scores 1, 1/2, 1/3 pass 0.3
+    with pytest.raises(fv.session.SessionError):
+        s.search([0.0, 1.0], 3)               # session.rs:216-223
+    with pytest.raises(fv.session.SessionError):
+        s.add_vectors([{"id": "bad", "vector": [1.0, 2.0]}])
+    with pytest.raises(fv.session.SessionError):
+        s.add_vectors([{"id": "doc-1", "vector": [9.0, 9.0, 9.0]}])   # duplicate id
+    s.delete_vector("doc-0")
+    assert s.search([0.0, 1.0, 0.5], 1)[0]["id"] == "doc-1"
+    # REST shape (src/api/rest.rs:116-130, 650-676)
+    r = fv.rest_search(s.index, {"vector": [2.0, 1.0, 0.5], "k": 3, "options": {"score_threshold": 0.4}})
+    assert set(r) == {"results", "search_time_ms", "indices_searched", "partial_results"}
+    assert r["indices_searched"] == 2 and r["partial_results"] is False
+    assert [x["distance"] for x in r["results"]] == [0.0, 1.0, 1.0][:len(r["results"])]
+    assert all(x["score"] >= 0.4 and set(x) == {"id", "distance", "score"} for x in r["results"])
+    s.destroy()
+    with pytest.raises(fv.session.SessionError):
+        s.search([0.0, 1.0, 0.5], 1)
