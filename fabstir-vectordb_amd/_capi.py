@@ -37,6 +37,8 @@ SIGNATURES = {
     "fvdb_timer_start": (i32, [vp]),
     "fvdb_timer_stop_ms": (i32, [vp, f32p]),
     "fvdb_ctx_set_profiling": (i32, [vp, i32]),
+    "fvdb_dot_products": (i32, [vp, f32p, u32, f32p, u64, u32, f32p]),
+    "fvdb_cosine_similarities": (i32, [vp, f32p, u32, f32p, u64, u32, f32p]),
     "fvdb_ivf_create": (i32, [vp, u32, u32, C.POINTER(vp)]),
     "fvdb_ivf_destroy": (None, [vp]),
     "fvdb_ivf_set_centroids": (i32, [vp, f32p]),

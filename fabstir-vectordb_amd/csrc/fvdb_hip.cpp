@@ -546,6 +546,47 @@ int fvdb_timer_stop_ms(fvdb_ctx* ctx, float* out_ms) {
 }
 
 // =============================================================================================
+// similarity utilities (a3)
+// =============================================================================================
+static int dot_cosine(fvdb_ctx* ctx, const float* q, uint32_t B, const float* x, uint64_t n, uint32_t d, float* out,
+                      int cosine) {
+  if (!ctx || !q || !x || !out || d == 0) return FVDB_E_INVALID;
+  if (B == 0 || n == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = check_finite(ctx, q, (uint64_t)B * d);
+  if (rc) return rc;
+  rc = check_finite(ctx, x, n * d);
+  if (rc) return rc;
+  float *dq = nullptr, *dx = nullptr, *dout = nullptr;
+  auto done = [&]() {
+    if (dq) (void)hipFree(dq);
+    if (dx) (void)hipFree(dx);
+    if (dout) (void)hipFree(dout);
+  };
+  if (hipMalloc(&dq, (size_t)B * d * 4) != hipSuccess || hipMalloc(&dx, n * d * 4) != hipSuccess ||
+      hipMalloc(&dout, (size_t)B * n * 4) != hipSuccess) {
+    done();
+    FAIL(ctx, FVDB_E_OOM, "similarity scratch allocation failed");
+  }
+  (void)hipMemcpyAsync(dq, q, (size_t)B * d * 4, hipMemcpyHostToDevice, ctx->stream);
+  (void)hipMemcpyAsync(dx, x, n * d * 4, hipMemcpyHostToDevice, ctx->stream);
+  hipLaunchKernelGGL(dot_cosine_kernel, dim3(cdiv((uint64_t)B * n, 256)), dim3(256), 0, ctx->stream, dq, dx, B, n, d,
+                     cosine, dout);
+  hipError_t e = hipMemcpyAsync(out, dout, (size_t)B * n * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  done();
+  if (e != hipSuccess) FAIL(ctx, FVDB_E_HIP, hipGetErrorString(e));
+  return FVDB_OK;
+}
+int fvdb_dot_products(fvdb_ctx* ctx, const float* q, uint32_t B, const float* x, uint64_t n, uint32_t d, float* out) {
+  return dot_cosine(ctx, q, B, x, n, d, out, 0);
+}
+int fvdb_cosine_similarities(fvdb_ctx* ctx, const float* q, uint32_t B, const float* x, uint64_t n, uint32_t d,
+                             float* out) {
+  return dot_cosine(ctx, q, B, x, n, d, out, 1);
+}
+
+// =============================================================================================
 // IVF
 // =============================================================================================
 int fvdb_ivf_create(fvdb_ctx* ctx, uint32_t d, uint32_t nlist, fvdb_ivf** out) {

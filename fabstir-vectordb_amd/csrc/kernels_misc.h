@@ -89,6 +89,35 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(const float* __re
   out[(size_t)b * stride + c] = res;
 }
 
+// ---- a3 utilities: batched dot product / cosine similarity, B queries x n rows -------------------
+// dot_product_scalar (src/core/vector_ops.rs:35-37) is a left-to-right f32 fold of products;
+// cosine_similarity_scalar (:39-49) = dot / (sqrt(dot(a,a)) * sqrt(dot(b,b))), 0 when a norm is 0.
+// One lane per (query, row) pair folds sequentially, so results equal the reference's bit for bit.
+__global__ __launch_bounds__(256) void dot_cosine_kernel(const float* __restrict__ q, const float* __restrict__ x,
+                                                         uint32_t B, uint64_t n, uint32_t d, int cosine,
+                                                         float* __restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (uint64_t)B * n) return;
+  const uint32_t b = (uint32_t)(t / n);
+  const uint64_t r = t - (uint64_t)b * n;
+  const float* a = q + (size_t)b * d;
+  const float* c = x + r * d;
+  float dot = 0.0f, na = 0.0f, nb = 0.0f;
+  for (uint32_t j = 0; j < d; ++j) {
+    dot = dot + a[j] * c[j];
+    if (cosine) {
+      na = na + a[j] * a[j];
+      nb = nb + c[j] * c[j];
+    }
+  }
+  float res = dot;
+  if (cosine) {
+    const float sa = sqrtf(na), sb = sqrtf(nb);
+    res = (sa == 0.0f || sb == 0.0f) ? 0.0f : dot / (sa * sb);
+  }
+  out[t] = res;
+}
+
 // ---- k-means (src/ivf/core.rs:388-429): sums in data order, like the reference --------------
 // One block per cluster; thread t owns dims t, t+256, ...; every thread walks the assignment
 // array (wave-uniform branch) and adds member rows in data order.

@@ -141,6 +141,29 @@ class Context:
         return ms.value
 
 
+def _pairwise(ctx, fn, q, x):
+    q, x = _f32(q), _f32(x)
+    if q.ndim == 1:
+        q = q.reshape(1, -1)
+    if x.ndim == 1:
+        x = x.reshape(1, -1)
+    if q.shape[1] != x.shape[1]:
+        raise DimensionMismatch(f"Dimension mismatch: {q.shape[1]} != {x.shape[1]}")
+    out = np.empty((q.shape[0], x.shape[0]), np.float32)
+    ctx.check(fn(ctx.h, _ptr(q, f32p), q.shape[0], _ptr(x, f32p), x.shape[0], q.shape[1], _ptr(out, f32p)))
+    return out
+
+
+def dot_products(ctx, q, x):
+    """dot_product_scalar for every (query, row) pair (src/core/vector_ops.rs:35-37)."""
+    return _pairwise(ctx, ctx.lib.fvdb_dot_products, q, x)
+
+
+def batch_cosine_similarity(ctx, q, x):
+    """batch_cosine_similarity / cosine_similarity_scalar (src/core/vector_ops.rs:8-10,39-49)."""
+    return _pairwise(ctx, ctx.lib.fvdb_cosine_similarities, q, x)
+
+
 class DeviceIVF:
     """IVF-flat index resident in HBM (fvdb_ivf): centroids + paged inverted lists."""
 

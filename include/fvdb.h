@@ -80,6 +80,15 @@ int fvdb_timer_stop_ms(fvdb_ctx* ctx, float* out_ms);
  * in with fvdb_ivf_profile_collect() after its own synchronisation point (no extra sync). */
 int fvdb_ctx_set_profiling(fvdb_ctx* ctx, int on);
 
+/* ---- similarity utilities ------------------------------------------------------------
+ * dot_product_scalar / cosine_similarity_scalar / batch_cosine_similarity
+ * (src/core/vector_ops.rs:8-10,35-49; Embedding::cosine_similarity src/core/types.rs:79-103):
+ * B queries x n rows -> out[B x n], sequential f32 folds (bit-identical to the reference).
+ * No index calls these in the reference; they are part of its public vector_ops surface. */
+int fvdb_dot_products(fvdb_ctx* ctx, const float* q, uint32_t B, const float* x, uint64_t n, uint32_t d, float* out);
+int fvdb_cosine_similarities(fvdb_ctx* ctx, const float* q, uint32_t B, const float* x, uint64_t n, uint32_t d,
+                             float* out);
+
 /* ---- IVF-flat ------------------------------------------------------------------------
  * Replaces IVFIndex's arithmetic: find_nearest_centroid (src/ivf/core.rs:373-386), the
  * coarse ranking + list scan + selection of search_with_config (:626-681) and

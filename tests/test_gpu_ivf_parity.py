@@ -177,3 +177,26 @@ def test_incremental_adds_match_bulk(fv, ctx):
         cpu.batch_insert(ids[s:s + 333], x[s:s + 333])
     q = mixture(30, d, seed=42)
     assert_same(gpu.search(q, 10, 3), cpu.batch_search(q, 10, 3))
+
+
+def test_dot_and_cosine_utilities(fv, ctx):
+    # a3: dot_product_scalar / cosine_similarity_scalar (src/core/vector_ops.rs:35-49), bit-identical folds
+    # tests/core/vector_ops.rs:12-26, tests/core/vector_ops_advanced.rs:13-45
+    q = np.array([[1.0, 0.0, 0.0]], np.float32)
+    x = np.array([[1, 0, 0], [0, 1, 0], [0.707, 0.707, 0], [0, 0, 0]], np.float32)
+    sims = fv.engine.batch_cosine_similarity(ctx, q, x)[0]
+    assert abs(sims[0] - 1.0) < 1e-6 and abs(sims[1]) < 1e-6 and abs(sims[2] - 0.707) < 0.01 and sims[3] == 0.0
+    for size in (16, 64, 128, 256, 512, 1024):
+        a = np.sin(np.arange(size, dtype=np.float32)).astype(np.float32)
+        b = np.cos(np.arange(size, dtype=np.float32)).astype(np.float32)
+        assert fv.engine.dot_products(ctx, a, b)[0, 0] == np.float32(orc.dot_product_scalar(a, b))
+    ones = np.ones((1, 256), np.float32)
+    assert fv.engine.dot_products(ctx, ones, ones)[0, 0] == 256.0
+    assert abs(fv.engine.batch_cosine_similarity(ctx, ones, ones)[0, 0] - 1.0) < 1e-6
+    qq, xx = mixture(7, 96, seed=201), mixture(33, 96, seed=202)
+    dots, coss = fv.engine.dot_products(ctx, qq, xx), fv.engine.batch_cosine_similarity(ctx, qq, xx)
+    for i in range(7):
+        for j in range(33):
+            assert dots[i, j] == np.float32(orc.dot_product_scalar(qq[i], xx[j]))
+            assert coss[i, j] == np.float32(orc.cosine_similarity_scalar(qq[i], xx[j]))
+            assert -1.0 - 1e-6 <= coss[i, j] <= 1.0 + 1e-6
