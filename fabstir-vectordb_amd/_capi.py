@@ -40,6 +40,7 @@ SIGNATURES = {
     "fvdb_dot_products": (i32, [vp, f32p, u32, f32p, u64, u32, f32p]),
     "fvdb_cosine_similarities": (i32, [vp, f32p, u32, f32p, u64, u32, f32p]),
     "fvdb_ivf_create": (i32, [vp, u32, u32, C.POINTER(vp)]),
+    "fvdb_ivf_create_ex": (i32, [vp, u32, u32, i32, C.POINTER(vp)]),
     "fvdb_ivf_destroy": (None, [vp]),
     "fvdb_ivf_set_centroids": (i32, [vp, f32p]),
     "fvdb_ivf_get_centroids": (i32, [vp, f32p]),

@@ -13,7 +13,7 @@ constexpr uint32_t kInf32 = 0xFFFFFFFFu;  // "no candidate" key half (never a fi
 //   data[(block * d4 + chunk) * 64 + lane] is a float4 = dims 4*chunk .. 4*chunk+3 of row `lane`.
 // d is padded to a multiple of 4 with zeros (adding (0-0)^2 = +0 leaves an f32 sum unchanged).
 struct PoolView {
-  const float4* data;
+  const void* data;       // float4 chunks (f32 rows) or 8-half chunks (fp16 rows)
   const uint64_t* ids;    // [blocks][64] caller's row ids
   const uint64_t* valid;  // [blocks] bit l set = lane l holds a live (inserted, not deleted) row
   uint32_t d4;            // number of float4 chunks per row

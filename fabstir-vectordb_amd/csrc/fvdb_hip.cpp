@@ -95,12 +95,13 @@ static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b -
 
 // A pool of 64-row blocks in HBM (layout: common.h PoolView).
 struct Pool {
-  uint32_t d4 = 0;
+  uint32_t d4 = 0;      // 4-dim chunks per row (of the padded dimension)
+  uint32_t esize = 4;   // bytes per stored element: 4 = f32, 2 = fp16
   uint32_t cap_blocks = 0, used_blocks = 0;
-  float4* data = nullptr;
+  void* data = nullptr;
   uint64_t* ids = nullptr;
   uint64_t* valid = nullptr;
-  size_t block_f4() const { return (size_t)d4 * 64; }
+  size_t block_bytes() const { return (size_t)d4 * 4 * esize * 64; }
   PoolView view() const { return PoolView{data, ids, valid, d4}; }
   void release() {
     if (data) (void)hipFree(data);
@@ -115,16 +116,15 @@ struct Pool {
   int reserve(fvdb_ctx* ctx, uint32_t blocks) {
     if (blocks <= cap_blocks) return FVDB_OK;
     uint32_t ncap = std::max<uint32_t>(blocks, cap_blocks + cap_blocks / 2 + 16);
-    float4* nd = nullptr;
+    void* nd = nullptr;
     uint64_t* ni = nullptr;
     uint64_t* nv = nullptr;
-    HIPCHK(ctx, hipMalloc(&nd, (size_t)ncap * block_f4() * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&nd, (size_t)ncap * block_bytes()));
     HIPCHK(ctx, hipMalloc(&ni, (size_t)ncap * 64 * sizeof(uint64_t)));
     HIPCHK(ctx, hipMalloc(&nv, (size_t)ncap * sizeof(uint64_t)));
     HIPCHK(ctx, hipMemsetAsync(nv, 0, (size_t)ncap * sizeof(uint64_t), ctx->stream));
     if (used_blocks) {
-      HIPCHK(ctx, hipMemcpyAsync(nd, data, (size_t)used_blocks * block_f4() * sizeof(float4),
-                                 hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(nd, data, (size_t)used_blocks * block_bytes(), hipMemcpyDeviceToDevice, ctx->stream));
       HIPCHK(ctx, hipMemcpyAsync(ni, ids, (size_t)used_blocks * 64 * sizeof(uint64_t), hipMemcpyDeviceToDevice,
                                  ctx->stream));
       HIPCHK(ctx, hipMemcpyAsync(nv, valid, (size_t)used_blocks * sizeof(uint64_t), hipMemcpyDeviceToDevice,
@@ -146,6 +146,7 @@ struct fvdb_ivf {
   fvdb_ctx* ctx = nullptr;
   uint32_t d = 0, dpad = 0, d4 = 0, nlist = 0;
   bool trained = false;
+  bool f16 = false;  // inverted-list rows stored as fp16 (centroids and queries stay f32)
 
   // centroid table: row-major copy (host + device) and a blocked pool scanned as "list 0"
   std::vector<float> h_centroids;
@@ -223,28 +224,33 @@ struct ScanLaunch {
   uint32_t dpad, segb, k, nprobe, maxsegs;
   uint2* part;
   uint32_t max_items = 0;  // host-side upper bound on work items (0 = unknown): sizes the persistent grid
+  bool f16 = false;        // rows of `pool` are fp16
 };
 
 inline int kr_for(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : 4); }
 inline uint32_t q_for(uint32_t k) { return k <= 64 ? 16u : (k <= 128 ? 8u : 4u); }
 
-template <int Q, int KR, int ROLE>
+template <int Q, int KR, int ROLE, int ST>
 void launch_scan_t(fvdb_ctx* ctx, const ScanLaunch& s) {
   static const uint32_t wgs_per_cu = getenv("FVDB_SCAN_WGS_PER_CU") ? (uint32_t)atoi(getenv("FVDB_SCAN_WGS_PER_CU")) : 8u;
   uint32_t grid = (uint32_t)ctx->num_cus * wgs_per_cu;  // more than fit: surplus workgroups find the queue empty
   if (s.max_items) grid = std::min(grid, std::max<uint32_t>(1u, (s.max_items + 3) / 4));  // 4 waves per workgroup
-  hipLaunchKernelGGL((scan_topk_kernel<Q, KR, ROLE>), dim3(grid), dim3(256), 0, ctx->stream, s.pool.data, s.pool.valid,
+  hipLaunchKernelGGL((scan_topk_kernel<Q, KR, ROLE, ST>), dim3(grid), dim3(256), 0, ctx->stream, s.pool.data, s.pool.valid,
                      s.pool.d4, s.list_off, s.list_blocks, s.nlist, s.entry_off, s.item_off, (const u32x2*)s.entries,
                      s.n_items, s.head, s.queries, s.dpad, s.segb, s.k, s.nprobe, s.maxsegs, (u32x2*)s.part);
 }
 
+template <int ROLE, int ST>
+void launch_scan_rs(fvdb_ctx* ctx, const ScanLaunch& s) {
+  switch (kr_for(s.k)) {
+    case 1: launch_scan_t<16, 1, ROLE, ST>(ctx, s); break;
+    case 2: launch_scan_t<8, 2, ROLE, ST>(ctx, s); break;
+    default: launch_scan_t<4, 4, ROLE, ST>(ctx, s); break;
+  }
+}
 template <int ROLE>
 void launch_scan_r(fvdb_ctx* ctx, const ScanLaunch& s) {
-  switch (kr_for(s.k)) {
-    case 1: launch_scan_t<16, 1, ROLE>(ctx, s); break;
-    case 2: launch_scan_t<8, 2, ROLE>(ctx, s); break;
-    default: launch_scan_t<4, 4, ROLE>(ctx, s); break;
-  }
+  if (s.f16) launch_scan_rs<ROLE, 1>(ctx, s); else launch_scan_rs<ROLE, 0>(ctx, s);
 }
 enum { ROLE_COARSE = 0, ROLE_LIST = 1, ROLE_ALL = 2 };
 void launch_scan(fvdb_ctx* ctx, const ScanLaunch& s, int role) {
@@ -394,6 +400,7 @@ int run_fine(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t 
   ScanLaunch s{ivf->pool.view(), ivf->t_off.as<uint32_t>(), ivf->t_blocks.as<uint32_t>(), nlist,
                ivf->s_eoff.as<uint32_t>(), ivf->s_ioff.as<uint32_t>(), ivf->s_entries.as<uint2>(), scal + 2,
                scal + 3, qpad, ivf->dpad, segb, k, np, maxsegs, ivf->s_part.as<uint2>()};
+  s.f16 = ivf->f16;
   launch_scan(ctx, s, role);
   if (ctx->profiling) (void)hipEventRecord(ivf->sev[4], ctx->stream);
   MergeArgs m{};
@@ -590,8 +597,13 @@ int fvdb_cosine_similarities(fvdb_ctx* ctx, const float* q, uint32_t B, const fl
 // IVF
 // =============================================================================================
 int fvdb_ivf_create(fvdb_ctx* ctx, uint32_t d, uint32_t nlist, fvdb_ivf** out) {
+  return fvdb_ivf_create_ex(ctx, d, nlist, FVDB_F32, out);
+}
+
+int fvdb_ivf_create_ex(fvdb_ctx* ctx, uint32_t d, uint32_t nlist, int row_dtype, fvdb_ivf** out) {
   if (!ctx || !out) return FVDB_E_INVALID;
   *out = nullptr;
+  if (row_dtype != FVDB_F32 && row_dtype != FVDB_F16) FAIL(ctx, FVDB_E_INVALID, "row_dtype must be FVDB_F32 or FVDB_F16");
   if (d == 0 || nlist == 0) FAIL(ctx, FVDB_E_INVALID, "d and nlist must be > 0");
   if (d > 2048 * 4) FAIL(ctx, FVDB_E_INVALID, "d too large");
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -599,12 +611,14 @@ int fvdb_ivf_create(fvdb_ctx* ctx, uint32_t d, uint32_t nlist, fvdb_ivf** out) {
   if (!ivf) return FVDB_E_OOM;
   ivf->ctx = ctx;
   ivf->d = d;
-  ivf->d4 = (d + 3) / 4;
-  ivf->dpad = ivf->d4 * 4;
+  ivf->f16 = row_dtype == FVDB_F16;
+  ivf->dpad = ivf->f16 ? ((d + 15) / 16) * 16 : ((d + 3) / 4) * 4;  // fp16 rows: whole 16-dim steps
+  ivf->d4 = ivf->dpad / 4;
   ivf->nlist = nlist;
   ivf->list_blocks.assign(nlist, {});
   ivf->list_len.assign(nlist, 0);
   ivf->pool.d4 = ivf->d4;
+  ivf->pool.esize = ivf->f16 ? 2 : 4;
   ivf->cpool.d4 = ivf->d4;
   for (auto& e : ivf->sev) (void)hipEventCreate(&e);
   *out = ivf;
@@ -649,7 +663,7 @@ static int install_centroids(fvdb_ivf* ivf, const float* d_rowmajor /* device [n
   const uint64_t threads = (uint64_t)nlist * ivf->d4;
   hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, ctx->stream, d_rowmajor, ivf->d,
                      ivf->d4, (uint64_t)nlist, ivf->s_slots.as<uint32_t>(), (const uint64_t*)nullptr,
-                     ivf->cpool.data, ivf->cpool.ids, (unsigned long long*)ivf->cpool.valid);
+                     (float4*)ivf->cpool.data, ivf->cpool.ids, (unsigned long long*)ivf->cpool.valid);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ivf->trained = true;
@@ -779,10 +793,18 @@ static int append_staged(fvdb_ivf* ivf, const uint64_t* ids, uint64_t n, const u
   HIPCHK(ctx, ivf->s_ids.ensure(n * 8));
   HIPCHK(ctx, hipMemcpyAsync(ivf->s_slots.p, slots.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
   if (ids) HIPCHK(ctx, hipMemcpyAsync(ivf->s_ids.p, ids, n * 8, hipMemcpyHostToDevice, ctx->stream));
-  const uint64_t threads = n * ivf->d4;
-  hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, ctx->stream, ivf->s_in.as<float>(),
-                     ivf->d, ivf->d4, n, ivf->s_slots.as<uint32_t>(), ids ? ivf->s_ids.as<uint64_t>() : nullptr,
-                     ivf->pool.data, ivf->pool.ids, (unsigned long long*)ivf->pool.valid);
+  if (ivf->f16) {
+    const uint32_t d8 = ivf->dpad / 8;
+    hipLaunchKernelGGL(scatter_rows_f16_kernel, dim3(cdiv(n * d8, 256)), dim3(256), 0, ctx->stream,
+                       ivf->s_in.as<float>(), ivf->d, d8, n, ivf->s_slots.as<uint32_t>(),
+                       ids ? ivf->s_ids.as<uint64_t>() : nullptr, ivf->pool.data, ivf->pool.ids,
+                       (unsigned long long*)ivf->pool.valid);
+  } else {
+    const uint64_t threads = n * ivf->d4;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, ctx->stream, ivf->s_in.as<float>(),
+                       ivf->d, ivf->d4, n, ivf->s_slots.as<uint32_t>(), ids ? ivf->s_ids.as<uint64_t>() : nullptr,
+                       (float4*)ivf->pool.data, ivf->pool.ids, (unsigned long long*)ivf->pool.valid);
+  }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FVDB_OK;

@@ -30,6 +30,31 @@ __global__ void scatter_rows_kernel(const float* __restrict__ src, uint32_t d, u
   }
 }
 
+// Same for fp16 row storage: one thread per (row, 8-dim chunk), f32 -> fp16 round-to-nearest-even.
+__global__ void scatter_rows_f16_kernel(const float* __restrict__ src, uint32_t d, uint32_t d8, uint64_t n,
+                                        const uint32_t* __restrict__ dst_slot, const uint64_t* __restrict__ row_ids,
+                                        void* __restrict__ pool_data, uint64_t* __restrict__ pool_ids,
+                                        unsigned long long* __restrict__ pool_valid) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t i = t / d8;
+  const uint32_t c = (uint32_t)(t % d8);
+  if (i >= n) return;
+  const uint32_t slot = dst_slot[i];
+  const uint32_t blk = slot >> 6, lane = slot & 63;
+  h8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const uint32_t j = 8 * c + e;
+    v[e] = (_Float16)(j < d ? src[i * d + j] : 0.0f);
+  }
+  ((h8*)pool_data)[((size_t)blk * d8 + c) * 64 + lane] = v;
+  if (c == 0) {
+    pool_ids[(size_t)blk * 64 + lane] = row_ids ? row_ids[i] : i;
+    atomicOr(pool_valid + blk, 1ull << lane);
+  }
+}
+
 // Soft delete / undelete: slots = block*64 + lane.
 __global__ void set_valid_kernel(const uint32_t* __restrict__ slots, uint64_t n, int deleted,
                                  unsigned long long* __restrict__ pool_valid) {

@@ -139,10 +139,38 @@ __device__ __forceinline__ void offer(WaveTopK<KR>& tk, uint32_t k, uint32_t chi
   }
 }
 
+// Row storage: ST = 0 rows are f32 (float4 chunks), ST = 1 rows are IEEE fp16 (8 halfs per 16-byte chunk,
+// d padded to a multiple of 16) widened to f32 in registers — the arithmetic after the load is the same
+// exact f32 fold either way (config C5: results equal the oracle run on the fp16-rounded rows).
+template <int ST>
+__device__ __forceinline__ void load_rows16(const void* __restrict__ pool_data, uint32_t blk, uint32_t d4, uint32_t c,
+                                            int lane, float (&x)[16]) {
+  if (ST == 0) {
+    const float4* xp = (const float4*)pool_data + (size_t)blk * d4 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = xp[(size_t)(c + i) * 64];
+      x[4 * i + 0] = v.x;
+      x[4 * i + 1] = v.y;
+      x[4 * i + 2] = v.z;
+      x[4 * i + 3] = v.w;
+    }
+  } else {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const h8* xp = (const h8*)pool_data + (size_t)blk * (d4 >> 1) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const h8 v = xp[(size_t)((c >> 1) + i) * 64];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) x[8 * i + t] = (float)v[t];
+    }
+  }
+}
+
 // One work item: rows of blocks [b0, b1) of a list against the ne (<= QQ) queries of a group.
 // QQ in {16, 8, 4}: short groups run the narrower instantiation instead of padding to 16.
-template <int QQ, int KR>
-__device__ __forceinline__ void scan_item(const float4* __restrict__ pool_data, const uint64_t* __restrict__ pool_valid,
+template <int QQ, int KR, int ST>
+__device__ __forceinline__ void scan_item(const void* __restrict__ pool_data, const uint64_t* __restrict__ pool_valid,
                                           const uint32_t d4, const uint32_t* __restrict__ list_blocks,
                                           const u32x2* __restrict__ entries, const float* __restrict__ queries,
                                           const uint32_t dpad, const uint32_t k, const uint32_t nprobe,
@@ -162,22 +190,15 @@ __device__ __forceinline__ void scan_item(const float4* __restrict__ pool_data, 
 
   for (uint32_t b = b0; b < b1; ++b) {
     const uint32_t blk = cload(list_blocks + b_begin + b);
-    const float4* xp = pool_data + (size_t)blk * d4 * 64 + lane;
     float acc[QQ];
 #pragma unroll
     for (int j = 0; j < QQ; ++j) acc[j] = 0.0f;
-#ifndef FVDB_SCAN_VARIANT
-#define FVDB_SCAN_VARIANT 2
-#endif
-#if FVDB_SCAN_VARIANT == 2
     uint32_t c = 0;
     // 16 dims per step: one s_load_dwordx16 per query feeds 48 VALU ops, so the scalar-side address
     // arithmetic is 1/4 of a chunk-at-a-time loop's
     for (; c + 4 <= d4; c += 4) {
-      const float4 x0 = xp[(size_t)(c + 0) * 64];
-      const float4 x1 = xp[(size_t)(c + 1) * 64];
-      const float4 x2 = xp[(size_t)(c + 2) * 64];
-      const float4 x3 = xp[(size_t)(c + 3) * 64];
+      float x[16];
+      load_rows16<ST>(pool_data, blk, d4, c, lane, x);
       // query j+1's 16 dims are requested before query j's are consumed (scalar loads return out of
       // order, so the only usable wait is lgkmcnt(0): it lands after a 48-op compute block)
       f32x16 qn = cload16(queries + qoff[0] + 4 * c);
@@ -187,72 +208,27 @@ __device__ __forceinline__ void scan_item(const float4* __restrict__ pool_data, 
         if (j + 1 < QQ) qn = cload16(queries + qoff[j + 1] + 4 * c);
         __builtin_amdgcn_sched_barrier(0);  // keep the request ahead of the 48 ops it overlaps with
         float t, a = acc[j];
-        t = x0.x - qv[0]; a = a + t * t;
-        t = x0.y - qv[1]; a = a + t * t;
-        t = x0.z - qv[2]; a = a + t * t;
-        t = x0.w - qv[3]; a = a + t * t;
-        t = x1.x - qv[4]; a = a + t * t;
-        t = x1.y - qv[5]; a = a + t * t;
-        t = x1.z - qv[6]; a = a + t * t;
-        t = x1.w - qv[7]; a = a + t * t;
-        t = x2.x - qv[8]; a = a + t * t;
-        t = x2.y - qv[9]; a = a + t * t;
-        t = x2.z - qv[10]; a = a + t * t;
-        t = x2.w - qv[11]; a = a + t * t;
-        t = x3.x - qv[12]; a = a + t * t;
-        t = x3.y - qv[13]; a = a + t * t;
-        t = x3.z - qv[14]; a = a + t * t;
-        t = x3.w - qv[15]; a = a + t * t;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          t = x[i] - qv[i];
+          a = a + t * t;
+        }
         acc[j] = a;
       }
     }
-#elif FVDB_SCAN_VARIANT == 1
-    uint32_t c = 0;
-    // 16 dims per step: one s_load_dwordx16 per query feeds 48 VALU ops, so the scalar-side address
-    // arithmetic is 1/4 of a chunk-at-a-time loop's
-    for (; c + 4 <= d4; c += 4) {
-      const float4 x0 = xp[(size_t)(c + 0) * 64];
-      const float4 x1 = xp[(size_t)(c + 1) * 64];
-      const float4 x2 = xp[(size_t)(c + 2) * 64];
-      const float4 x3 = xp[(size_t)(c + 3) * 64];
-      // query j+1's 16 dims are requested before query j's are consumed (scalar loads return out of
-      // order, so the only usable wait is lgkmcnt(0): it lands after a 48-op compute block)
+    if (ST == 0) {
+      const float4* xp = (const float4*)pool_data + (size_t)blk * d4 * 64 + lane;
+      for (; c < d4; ++c) {  // d4 % 4 leftover chunks (f32 rows only; fp16 rows are padded to 16 dims)
+        const float4 xv = xp[(size_t)c * 64];
 #pragma unroll
-      for (int j = 0; j < QQ; ++j) {
-        const f32x16 qv = cload16(queries + qoff[j] + 4 * c);
-        float t, a = acc[j];
-        t = x0.x - qv[0]; a = a + t * t;
-        t = x0.y - qv[1]; a = a + t * t;
-        t = x0.z - qv[2]; a = a + t * t;
-        t = x0.w - qv[3]; a = a + t * t;
-        t = x1.x - qv[4]; a = a + t * t;
-        t = x1.y - qv[5]; a = a + t * t;
-        t = x1.z - qv[6]; a = a + t * t;
-        t = x1.w - qv[7]; a = a + t * t;
-        t = x2.x - qv[8]; a = a + t * t;
-        t = x2.y - qv[9]; a = a + t * t;
-        t = x2.z - qv[10]; a = a + t * t;
-        t = x2.w - qv[11]; a = a + t * t;
-        t = x3.x - qv[12]; a = a + t * t;
-        t = x3.y - qv[13]; a = a + t * t;
-        t = x3.z - qv[14]; a = a + t * t;
-        t = x3.w - qv[15]; a = a + t * t;
-        acc[j] = a;
-      }
-    }
-#else
-    uint32_t c = 0;
-#endif
-    for (; c < d4; ++c) {  // d4 % 4 leftover chunks
-      const float4 x = xp[(size_t)c * 64];
-#pragma unroll
-      for (int j = 0; j < QQ; ++j) {
-        const f32x4 qv = cload((const f32x4*)(queries + qoff[j] + 4 * c));
-        float t;
-        t = x.x - qv.x; acc[j] = acc[j] + t * t;
-        t = x.y - qv.y; acc[j] = acc[j] + t * t;
-        t = x.z - qv.z; acc[j] = acc[j] + t * t;
-        t = x.w - qv.w; acc[j] = acc[j] + t * t;
+        for (int j = 0; j < QQ; ++j) {
+          const f32x4 qv = cload((const f32x4*)(queries + qoff[j] + 4 * c));
+          float t;
+          t = xv.x - qv.x; acc[j] = acc[j] + t * t;
+          t = xv.y - qv.y; acc[j] = acc[j] + t * t;
+          t = xv.z - qv.z; acc[j] = acc[j] + t * t;
+          t = xv.w - qv.w; acc[j] = acc[j] + t * t;
+        }
       }
     }
     const uint64_t vmask = cload(pool_valid + blk);
@@ -299,9 +275,9 @@ __device__ __forceinline__ void scan_item(const float4* __restrict__ pool_data, 
 // -----------------------------------------------------------------------------------------
 // ROLE only names the instantiation (0 = coarse ranking over the centroid table, 1 = IVF list scan,
 // 2 = exhaustive scan) so that rocprof statistics separate the three uses of the same code.
-template <int Q, int KR, int ROLE>
+template <int Q, int KR, int ROLE, int ST>
 __global__ __launch_bounds__(256) void scan_topk_kernel(
-    const float4* __restrict__ pool_data, const uint64_t* __restrict__ pool_valid, const uint32_t d4,
+    const void* __restrict__ pool_data, const uint64_t* __restrict__ pool_valid, const uint32_t d4,
     const uint32_t* __restrict__ list_off, const uint32_t* __restrict__ list_blocks, const uint32_t nlist,
     const uint32_t* __restrict__ entry_off, const uint32_t* __restrict__ item_off,
     const u32x2* __restrict__ entries, const uint32_t* __restrict__ n_items_p, uint32_t* __restrict__ head,
@@ -335,13 +311,13 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(
     const uint32_t ne = min((uint32_t)Q, cnt - g * Q);
 
     if (ne <= 4)
-      scan_item<4, KR>(pool_data, pool_valid, d4, list_blocks, entries, queries, dpad, k, nprobe, maxsegs, part, b_begin,
+      scan_item<4, KR, ST>(pool_data, pool_valid, d4, list_blocks, entries, queries, dpad, k, nprobe, maxsegs, part, b_begin,
                        b0, b1, e0, ne, seg, lane);
     else if (ne <= 8)
-      scan_item<8, KR>(pool_data, pool_valid, d4, list_blocks, entries, queries, dpad, k, nprobe, maxsegs, part, b_begin,
+      scan_item<8, KR, ST>(pool_data, pool_valid, d4, list_blocks, entries, queries, dpad, k, nprobe, maxsegs, part, b_begin,
                        b0, b1, e0, ne, seg, lane);
     else
-      scan_item<(Q > 8 ? Q : 8), KR>(pool_data, pool_valid, d4, list_blocks, entries, queries, dpad, k, nprobe, maxsegs,
+      scan_item<(Q > 8 ? Q : 8), KR, ST>(pool_data, pool_valid, d4, list_blocks, entries, queries, dpad, k, nprobe, maxsegs,
                                      part, b_begin, b0, b1, e0, ne, seg, lane);
   }
 }

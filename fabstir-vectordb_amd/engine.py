@@ -167,11 +167,11 @@ def batch_cosine_similarity(ctx, q, x):
 class DeviceIVF:
     """IVF-flat index resident in HBM (fvdb_ivf): centroids + paged inverted lists."""
 
-    def __init__(self, ctx, d, nlist):
+    def __init__(self, ctx, d, nlist, dtype="f32"):
         self.ctx, self.lib = ctx, ctx.lib
-        self.d, self.nlist = int(d), int(nlist)
+        self.d, self.nlist, self.dtype = int(d), int(nlist), dtype
         h = C.c_void_p()
-        ctx.check(self.lib.fvdb_ivf_create(ctx.h, self.d, self.nlist, C.byref(h)))
+        ctx.check(self.lib.fvdb_ivf_create_ex(ctx.h, self.d, self.nlist, {"f32": 0, "f16": 1}[dtype], C.byref(h)))
         self.h = h
 
     def close(self):

@@ -95,6 +95,11 @@ int fvdb_cosine_similarities(fvdb_ctx* ctx, const float* q, uint32_t B, const fl
  * batch_search (src/ivf/operations.rs:132-145).  Row ids are caller-chosen u64.
  */
 int fvdb_ivf_create(fvdb_ctx* ctx, uint32_t d, uint32_t nlist, fvdb_ivf** out);
+/* Row storage of the inverted lists.  FVDB_F16 (config C5) keeps rows as IEEE fp16 (rounded to nearest
+ * even at insert) and widens them to f32 in registers; centroids, queries, the f32 fold and the ordering
+ * are unchanged, so results equal the reference algorithm run on the fp16-rounded rows. */
+typedef enum fvdb_dtype { FVDB_F32 = 0, FVDB_F16 = 1 } fvdb_dtype;
+int fvdb_ivf_create_ex(fvdb_ctx* ctx, uint32_t d, uint32_t nlist, int row_dtype, fvdb_ivf** out);
 void fvdb_ivf_destroy(fvdb_ivf* ivf);
 /* set_trained (src/ivf/core.rs:509-520): install nlist x d centroids (host), empty the lists. */
 int fvdb_ivf_set_centroids(fvdb_ivf* ivf, const float* centroids);

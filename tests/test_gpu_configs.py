@@ -117,3 +117,37 @@ def test_c3_scale_properties_hybrid(fv, ctx):
     lo = hyb.search(q, k, now=now, hnsw_ef=50, ivf_n_probe=4, search_recent=False)
     hi = hyb.search(q, k, now=now, hnsw_ef=50, ivf_n_probe=64, search_recent=False)
     assert np.all(hi.distances[:, k - 1] <= lo.distances[:, k - 1])  # probing more lists can only improve the k-th
+
+
+@pytest.mark.parametrize("d", [768, 100])
+def test_c5_fp16_rows_ivf_flat(fv, ctx, d):
+    # BASELINE.json configs[4] shape (768-d fp16 rows, IVF-flat) at test size.  The reference is f32-only;
+    # the contract (SURVEY.md section 7 "hard parts") is agreement with the reference algorithm run on the
+    # fp16-rounded rows with f32 accumulation: ids identical, distances bit-identical.
+    n, nlist, nprobe, B, k = 20_000, 128, 16, 128, 10
+    x = mixture(n, d, n_comp=64, sigma=0.6, seed=131)
+    x16 = x.astype(np.float16).astype(np.float32)  # round-to-nearest-even, like the insert kernel
+    ids = np.arange(n, dtype=np.uint64)
+    cents = x[:nlist].copy()
+    gpu = fv.DeviceIVF(ctx, d, nlist, dtype="f16")
+    gpu.set_centroids(cents)
+    cl, pos = gpu.add(x, ids)
+    cpu = orc.IVFIndex(n_clusters=nlist, n_probe=nprobe)
+    cpu.set_trained(cents)
+    cpu.batch_insert_assigned(ids, x16, cl)
+    q = mixture(B, d, n_comp=64, sigma=0.6, seed=132)
+    for kk, npb in ((k, nprobe), (1, 1), (100, 8)):
+        gi, gd, gc = gpu.search(q, kk, npb)
+        ci, cd, cc = cpu.batch_search(q, kk, npb, threads=4)
+        assert np.array_equal(gc, cc) and np.array_equal(gi, ci) and np.array_equal(bits(gd), bits(cd))
+    # against exact f32 ground truth: fp16 rounding barely moves the neighbour sets
+    f32 = fv.DeviceIVF(ctx, d, nlist)
+    f32.set_centroids(cents)
+    f32.add(x, ids)
+    ei = f32.search_all(q, k)[0]
+    ai = gpu.search_all(q, k)[0]
+    recall = np.mean([len(set(ei[b].tolist()) & set(ai[b].tolist())) / k for b in range(B)])
+    assert recall > 0.97
+    dead = np.arange(0, n, 7)
+    gpu.set_deleted(cl[dead], pos[dead], True)
+    assert not np.isin(gpu.search(q, k, nprobe)[0], dead.astype(np.uint64)).any()
