@@ -17,6 +17,7 @@
 #include "kernels_graph.h"
 #include "kernels_misc.h"
 #include "kernels_scan.h"
+#include "kernels_coarse.h"
 
 using namespace fvdb;
 
@@ -151,6 +152,10 @@ struct fvdb_ivf {
   // centroid table: row-major copy (host + device) and a blocked pool scanned as "list 0"
   std::vector<float> h_centroids;
   DBuf d_centroids_rm;   // [nlist][d]
+  DBuf d_cent_pad;       // [nlist][dpad] zero padded (only when d != dpad)
+  DBuf d_cnorm, d_cnmax; // |c|^2 per centroid, max |c|^2 (matrix-core coarse stage)
+  DBuf s_qnorm, s_A, s_fallbacks;
+  int coarse_mode = 0;   // 0 = matrix cores + exact verification when applicable, 1 = exact scan only
   Pool cpool;
   DBuf c_off, c_blocks, c_glob;  // single-list table for the centroid pool
 
@@ -320,6 +325,28 @@ int padded_queries(fvdb_ivf* ivf, const float* q_dev, uint32_t B, const float** 
 // Writes u32 cluster ids to out_probes[B][kc] (probe order) and, optionally, their distances.
 int run_coarse(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t kc, uint32_t* out_probes, float* out_dist) {
   fvdb_ctx* ctx = ivf->ctx;
+  static const bool env_exact = getenv("FVDB_COARSE_EXACT") != nullptr;  // tuning aid
+  if (ivf->coarse_mode == 0 && !env_exact && ivf->dpad % 16 == 0 && kc <= 48 && ivf->nlist >= 64 && B > 0 &&
+      (uint64_t)B * ivf->nlist < (1ull << 31)) {
+    // matrix cores propose 64 candidates per query; the reference's arithmetic decides (kernels_coarse.h)
+    const uint32_t nlist = ivf->nlist;
+    const float* cpad = ivf->d == ivf->dpad ? ivf->d_centroids_rm.as<float>() : ivf->d_cent_pad.as<float>();
+    HIPCHK(ctx, ivf->s_qnorm.ensure((size_t)B * 4));
+    HIPCHK(ctx, ivf->s_A.ensure((size_t)B * nlist * 4));
+    if (ctx->profiling) (void)hipEventRecord(ivf->sev[0], ctx->stream);
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, qpad, ivf->dpad, ivf->dpad, B,
+                       ivf->s_qnorm.as<float>());
+    const uint32_t waves = cdiv(B, 32) * cdiv(nlist, 64);
+    hipLaunchKernelGGL(coarse_gemm_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, qpad, cpad,
+                       ivf->s_qnorm.as<float>(), ivf->d_cnorm.as<float>(), B, nlist, ivf->dpad, ivf->s_A.as<float>());
+    if (ctx->profiling) (void)hipEventRecord(ivf->sev[1], ctx->stream);
+    hipLaunchKernelGGL(coarse_select_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, ivf->s_A.as<float>(), qpad, cpad,
+                       ivf->s_qnorm.as<float>(), ivf->d_cnmax.as<float>(), B, nlist, ivf->d, ivf->dpad, 64u, kc,
+                       out_probes, out_dist, ivf->s_fallbacks.as<uint32_t>());
+    if (ctx->profiling) (void)hipEventRecord(ivf->sev[2], ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    return FVDB_OK;
+  }
   const uint32_t cblocks = ivf->cpool.used_blocks;
   const uint32_t segb = 1, Q = q_for(kc);
   const uint32_t maxsegs = cblocks;
@@ -631,7 +658,8 @@ void fvdb_ivf_destroy(fvdb_ivf* ivf) {
   (void)hipStreamSynchronize(ivf->ctx->stream);
   ivf->pool.release();
   ivf->cpool.release();
-  DBuf* bufs[] = {&ivf->d_centroids_rm, &ivf->c_off, &ivf->c_blocks, &ivf->c_glob, &ivf->t_off, &ivf->t_blocks,
+  DBuf* bufs[] = {&ivf->d_cent_pad, &ivf->d_cnorm, &ivf->d_cnmax, &ivf->s_qnorm, &ivf->s_A, &ivf->s_fallbacks,
+                  &ivf->d_centroids_rm, &ivf->c_off, &ivf->c_blocks, &ivf->c_glob, &ivf->t_off, &ivf->t_blocks,
                   &ivf->t_glob, &ivf->t_len, &ivf->s_q, &ivf->s_cpart, &ivf->s_probes, &ivf->s_cnt, &ivf->s_fill, &ivf->s_eoff,
                   &ivf->s_ioff, &ivf->s_entries, &ivf->s_part, &ivf->s_scalars, &ivf->s_ceoff, &ivf->s_cioff,
                   &ivf->s_in, &ivf->s_slots, &ivf->s_ids, &ivf->s_clusters, &ivf->s_out_ids, &ivf->s_out_dist,
@@ -664,6 +692,23 @@ static int install_centroids(fvdb_ivf* ivf, const float* d_rowmajor /* device [n
   hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, ctx->stream, d_rowmajor, ivf->d,
                      ivf->d4, (uint64_t)nlist, ivf->s_slots.as<uint32_t>(), (const uint64_t*)nullptr,
                      (float4*)ivf->cpool.data, ivf->cpool.ids, (unsigned long long*)ivf->cpool.valid);
+  // matrix-core coarse stage: padded row-major table, |c|^2, max |c|^2
+  const float* cpad = d_rowmajor;
+  if (ivf->d != ivf->dpad) {
+    HIPCHK(ctx, ivf->d_cent_pad.ensure((size_t)nlist * ivf->dpad * 4));
+    const uint64_t tot = (uint64_t)nlist * ivf->dpad;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, ctx->stream, d_rowmajor, ivf->d, ivf->dpad,
+                       (uint64_t)nlist, ivf->d_cent_pad.as<float>());
+    cpad = ivf->d_cent_pad.as<float>();
+  }
+  HIPCHK(ctx, ivf->d_cnorm.ensure((size_t)nlist * 4));
+  HIPCHK(ctx, ivf->d_cnmax.ensure(4));
+  HIPCHK(ctx, ivf->s_fallbacks.ensure(4));
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(nlist, 256)), dim3(256), 0, ctx->stream, cpad, ivf->dpad, ivf->dpad,
+                     nlist, ivf->d_cnorm.as<float>());
+  hipLaunchKernelGGL(max_f32_kernel, dim3(1), dim3(64), 0, ctx->stream, ivf->d_cnorm.as<float>(), nlist,
+                     ivf->d_cnmax.as<float>());
+  HIPCHK(ctx, hipMemsetAsync(ivf->s_fallbacks.p, 0, 4, ctx->stream));
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ivf->trained = true;
@@ -965,6 +1010,25 @@ int fvdb_ivf_coarse(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t nprobe, 
   if (out_dist)
     HIPCHK(ctx, hipMemcpyAsync(out_dist, ivf->s_cdist.p, (size_t)B * np * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+
+int fvdb_ivf_set_coarse_mode(fvdb_ivf* ivf, int mode) {
+  if (!ivf) return FVDB_E_INVALID;
+  if (mode != FVDB_COARSE_AUTO && mode != FVDB_COARSE_EXACT) FAIL(ivf->ctx, FVDB_E_INVALID, "unknown coarse mode");
+  ivf->coarse_mode = mode;
+  return FVDB_OK;
+}
+
+int fvdb_ivf_coarse_fallbacks(fvdb_ivf* ivf, uint64_t* out) {
+  fvdb_ctx* ctx = ivf->ctx;
+  *out = 0;
+  if (!ivf->s_fallbacks.p) return FVDB_OK;
+  uint32_t v = 0;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpyAsync(&v, ivf->s_fallbacks.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *out = v;
   return FVDB_OK;
 }
 

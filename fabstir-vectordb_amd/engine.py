@@ -289,6 +289,15 @@ class DeviceIVF:
         self.ctx.check(self.lib.fvdb_ivf_coarse(self.h, _ptr(q, f32p), q.shape[0], nprobe, _ptr(cl, u32p), _ptr(ds, f32p)))
         return cl, ds
 
+    def set_coarse_mode(self, mode):
+        """0 = matrix cores propose + exact verification (default), 1 = exact scan of every centroid."""
+        self.ctx.check(self.lib.fvdb_ivf_set_coarse_mode(self.h, int(mode)))
+
+    def coarse_fallbacks(self):
+        v = C.c_uint64(0)
+        self.ctx.check(self.lib.fvdb_ivf_coarse_fallbacks(self.h, C.byref(v)))
+        return int(v.value)
+
     def last_stats(self):
         st = _capi.SearchStats()
         self.ctx.check(self.lib.fvdb_ivf_last_stats(self.h, C.byref(st)))

@@ -155,6 +155,18 @@ int fvdb_ivf_search_all_dev(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint3
 int fvdb_ivf_coarse(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t nprobe, uint32_t* out_clusters,
                     float* out_dist);
 
+/* Coarse-stage implementation.  FVDB_COARSE_AUTO (default): the query x centroid contraction runs on the
+ * matrix cores (MFMA) to propose 64 candidate clusters per query, whose distances are then recomputed with
+ * the reference's sequential f32 arithmetic; a rounding-error bound proves the proposal contains the true
+ * top nprobe, otherwise that query is ranked exactly over the whole table.  Results are identical to
+ * FVDB_COARSE_EXACT (every centroid scored with the reference's arithmetic) by construction.  AUTO applies
+ * when padded d % 16 == 0, nprobe <= 48 and n_clusters >= 64; other shapes use the exact scan. */
+#define FVDB_COARSE_AUTO 0
+#define FVDB_COARSE_EXACT 1
+int fvdb_ivf_set_coarse_mode(fvdb_ivf* ivf, int mode);
+/* Queries (since the centroids were installed) whose proposal could not be proven and were ranked exactly. */
+int fvdb_ivf_coarse_fallbacks(fvdb_ivf* ivf, uint64_t* out);
+
 /* Counters of the last search on this index (for roofline accounting). */
 typedef struct fvdb_search_stats {
   uint64_t rows_scanned;      /* sum over queries of rows in probed lists (algorithmic) */
