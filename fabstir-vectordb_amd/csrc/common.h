@@ -62,6 +62,8 @@ struct MergeArgs {
   uint32_t* out_counts;   // [B] or nullptr
   uint64_t* out_keys;     // [B][k] or nullptr
   uint32_t* out_probes;   // [B][k] u32 ids (coarse stage) or nullptr
+  const uint32_t* qlist;  // when set: wave i handles query qlist[i], for i < *nq (exact rescan of a few queries)
+  const uint32_t* nq;
 };
 
 }  // namespace fvdb

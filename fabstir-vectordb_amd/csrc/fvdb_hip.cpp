@@ -18,6 +18,7 @@
 #include "kernels_misc.h"
 #include "kernels_scan.h"
 #include "kernels_coarse.h"
+#include "kernels_mfma.h"
 
 using namespace fvdb;
 
@@ -102,9 +103,16 @@ struct Pool {
   void* data = nullptr;
   uint64_t* ids = nullptr;
   uint64_t* valid = nullptr;
+  float* norms = nullptr;  // |x|^2 per row (matrix-core filter, kernels_mfma.h)
+  bool mirror = false;     // f32 pools: keep an fp16 (round-to-nearest) copy of the rows for the matrix-core filter
+  void* half = nullptr;    // [blocks][d8][64] 8-half chunks, same lane = row layout
   size_t block_bytes() const { return (size_t)d4 * 4 * esize * 64; }
   PoolView view() const { return PoolView{data, ids, valid, d4}; }
   void release() {
+    if (norms) (void)hipFree(norms);
+    norms = nullptr;
+    if (half) (void)hipFree(half);
+    half = nullptr;
     if (data) (void)hipFree(data);
     if (ids) (void)hipFree(ids);
     if (valid) (void)hipFree(valid);
@@ -120,7 +128,20 @@ struct Pool {
     void* nd = nullptr;
     uint64_t* ni = nullptr;
     uint64_t* nv = nullptr;
+    float* nn = nullptr;
     HIPCHK(ctx, hipMalloc(&nd, (size_t)ncap * block_bytes()));
+    // rows never written (the tail of each list's last block) must be finite: they share MFMA instructions with
+    // live rows, and 0 x NaN would poison those
+    HIPCHK(ctx, hipMemsetAsync(nd, 0, (size_t)ncap * block_bytes(), ctx->stream));
+    void* nh = nullptr;
+    if (mirror) {
+      HIPCHK(ctx, hipMalloc(&nh, (size_t)ncap * block_bytes() / 2));
+      HIPCHK(ctx, hipMemsetAsync(nh, 0, (size_t)ncap * block_bytes() / 2, ctx->stream));
+      if (used_blocks && half)
+        HIPCHK(ctx, hipMemcpyAsync(nh, half, (size_t)used_blocks * block_bytes() / 2, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    HIPCHK(ctx, hipMalloc(&nn, (size_t)ncap * 64 * sizeof(float)));
+    HIPCHK(ctx, hipMemsetAsync(nn, 0, (size_t)ncap * 64 * sizeof(float), ctx->stream));
     HIPCHK(ctx, hipMalloc(&ni, (size_t)ncap * 64 * sizeof(uint64_t)));
     HIPCHK(ctx, hipMalloc(&nv, (size_t)ncap * sizeof(uint64_t)));
     HIPCHK(ctx, hipMemsetAsync(nv, 0, (size_t)ncap * sizeof(uint64_t), ctx->stream));
@@ -130,11 +151,17 @@ struct Pool {
                                  ctx->stream));
       HIPCHK(ctx, hipMemcpyAsync(nv, valid, (size_t)used_blocks * sizeof(uint64_t), hipMemcpyDeviceToDevice,
                                  ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(nn, norms, (size_t)used_blocks * 64 * sizeof(float), hipMemcpyDeviceToDevice,
+                                 ctx->stream));
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (data) (void)hipFree(data);
     if (ids) (void)hipFree(ids);
     if (valid) (void)hipFree(valid);
+    if (norms) (void)hipFree(norms);
+    if (half) (void)hipFree(half);
+    half = nh;
+    norms = nn;
     data = nd;
     ids = ni;
     valid = nv;
@@ -156,6 +183,9 @@ struct fvdb_ivf {
   DBuf d_cnorm, d_cnmax; // |c|^2 per centroid, max |c|^2 (matrix-core coarse stage)
   DBuf s_qnorm, s_A, s_fallbacks;
   int coarse_mode = 0;   // 0 = matrix cores + exact verification when applicable, 1 = exact scan only
+  int scan_mode = 0;     // same choice for the inverted-list scan
+  DBuf d_xmax;           // max |x|^2 over the rows ever added (float bits)
+  DBuf s_qh, s_qn2, s_thr, s_tA, s_pa, s_surv, s_scnt, s_fail, s_mslots, s_sdist;
   Pool cpool;
   DBuf c_off, c_blocks, c_glob;  // single-list table for the centroid pool
 
@@ -334,7 +364,7 @@ int run_coarse(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t kc, uint32
     HIPCHK(ctx, ivf->s_qnorm.ensure((size_t)B * 4));
     HIPCHK(ctx, ivf->s_A.ensure((size_t)B * nlist * 4));
     if (ctx->profiling) (void)hipEventRecord(ivf->sev[0], ctx->stream);
-    hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, qpad, ivf->dpad, ivf->dpad, B,
+    hipLaunchKernelGGL(row_sqnorm_wave_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, qpad, ivf->dpad, ivf->dpad, B,
                        ivf->s_qnorm.as<float>());
     const uint32_t waves = cdiv(B, 32) * cdiv(nlist, 64);
     hipLaunchKernelGGL(coarse_gemm_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, qpad, cpad,
@@ -396,9 +426,10 @@ uint32_t pick_segb(fvdb_ivf* ivf, uint32_t B, uint32_t nprobe) {
   return 1;
 }
 
-// Fine stage for B queries whose probes[B][np] are already in HBM.
-int run_fine(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t np, const uint32_t* probes,
-             uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys, int role) {
+// Fine stage for B queries whose probes[B][np] are already in HBM: every row scored with the reference's fold.
+int run_fine_exact(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t np, const uint32_t* probes,
+                   uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys, int role,
+                   bool events = true) {
   fvdb_ctx* ctx = ivf->ctx;
   const uint32_t nlist = ivf->nlist;
   const uint32_t segb = pick_segb(ivf, B, np), Q = q_for(k);
@@ -423,13 +454,13 @@ int run_fine(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t 
                      (unsigned long long*)(scal + 4));
   hipLaunchKernelGGL(plan_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, probes, n, np,
                      ivf->s_eoff.as<uint32_t>(), ivf->s_fill.as<uint32_t>(), ivf->s_entries.as<uint2>());
-  if (ctx->profiling) (void)hipEventRecord(ivf->sev[3], ctx->stream);
+  if (ctx->profiling && events) (void)hipEventRecord(ivf->sev[3], ctx->stream);
   ScanLaunch s{ivf->pool.view(), ivf->t_off.as<uint32_t>(), ivf->t_blocks.as<uint32_t>(), nlist,
                ivf->s_eoff.as<uint32_t>(), ivf->s_ioff.as<uint32_t>(), ivf->s_entries.as<uint2>(), scal + 2,
                scal + 3, qpad, ivf->dpad, segb, k, np, maxsegs, ivf->s_part.as<uint2>()};
   s.f16 = ivf->f16;
   launch_scan(ctx, s, role);
-  if (ctx->profiling) (void)hipEventRecord(ivf->sev[4], ctx->stream);
+  if (ctx->profiling && events) (void)hipEventRecord(ivf->sev[4], ctx->stream);
   MergeArgs m{};
   m.pool = ivf->pool.view();
   m.lists = ListTable{ivf->t_off.as<uint32_t>(), ivf->t_blocks.as<uint32_t>(), nlist};
@@ -446,9 +477,201 @@ int run_fine(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t 
   m.out_counts = out_counts;
   m.out_keys = out_keys;
   launch_merge(ctx, m);
+  if (ctx->profiling && events) (void)hipEventRecord(ivf->sev[5], ctx->stream);
+  HIPCHK(ctx, hipGetLastError());
+  return FVDB_OK;
+}
+
+// Fine stage on the matrix cores (kernels_mfma.h): threshold from the nearest list, fp16 MFMA filter over all
+// probed lists, exact verification of the survivors, exact rescan of unproven queries.  Same outputs as
+// run_fine_exact.
+constexpr uint32_t kMfmaSlack = 6;     // phase A scores k + 6 rows
+constexpr uint32_t kMfmaCmax = 2048;   // survivor slots per query
+namespace {
+int env_u(const char* name, int dflt) { return getenv(name) ? atoi(getenv(name)) : dflt; }
+
+template <int MODE>
+void launch_mfma(fvdb_ctx* ctx, const MfmaScanArgs& a, int M, bool f16, uint32_t grid) {
+#define FVDB_MFMA_CASE(MM)                                                                                      \
+  if (f16) hipLaunchKernelGGL((scan_mfma_kernel<MM, 1, MODE>), dim3(grid), dim3(256), 0, ctx->stream, a);       \
+  else hipLaunchKernelGGL((scan_mfma_kernel<MM, 0, MODE>), dim3(grid), dim3(256), 0, ctx->stream, a)
+  if (M == 1) { FVDB_MFMA_CASE(1); }
+  else if (M == 2) { FVDB_MFMA_CASE(2); }
+  else { FVDB_MFMA_CASE(4); }
+#undef FVDB_MFMA_CASE
+}
+}  // namespace
+
+int run_fine_mfma(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t np, const uint32_t* probes,
+                  uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys) {
+  fvdb_ctx* ctx = ivf->ctx;
+  // tuning aids
+  static const int M_env = env_u("FVDB_MFMA_M", 2), segb_env = env_u("FVDB_MFMA_SEGB", 0),
+                   segbA_env = env_u("FVDB_MFMA_SEGB_A", 1), capA_env = env_u("FVDB_MFMA_CAP_A", 8), wgs_env = env_u("FVDB_MFMA_WGS_PER_CU", 2);
+  const int M = M_env >= 4 ? 4 : (M_env >= 2 ? 2 : 1);
+  const uint32_t Q = 16u * M;
+  const uint32_t nlist = ivf->nlist, ka = k + kMfmaSlack, cmax = kMfmaCmax;
+  const uint32_t segbA = std::max(1, segbA_env);
+  const uint32_t segb = segb_env > 0 ? (uint32_t)segb_env : pick_segb(ivf, B, np);
+  // partial lists of the exact rescan: same geometry as the exact scan's
+  const uint32_t fsegb = pick_segb(ivf, B, np), fmaxsegs = std::max<uint32_t>(1, cdiv(ivf->max_list_blocks, fsegb));
+  const uint64_t fpart = (uint64_t)B * np * fmaxsegs * k;
+  if (fpart >= (1ull << 32)) FAIL(ctx, FVDB_E_UNSUPPORTED, "batch too large for one launch (sub-batch it)");
+  HIPCHK(ctx, ivf->s_qh.ensure((size_t)(B + 1) * ivf->dpad * 2));
+  HIPCHK(ctx, ivf->s_qn2.ensure((size_t)B * 4));
+  HIPCHK(ctx, ivf->s_thr.ensure((size_t)B * 4));
+  HIPCHK(ctx, ivf->s_tA.ensure((size_t)B * 4));
+  HIPCHK(ctx, ivf->s_pa.ensure((size_t)B * 4));
+  HIPCHK(ctx, ivf->s_mslots.ensure((size_t)B * 64 * 4));
+  HIPCHK(ctx, ivf->s_surv.ensure((size_t)B * cmax * 8));
+  HIPCHK(ctx, ivf->s_sdist.ensure((size_t)B * cmax * 4));
+  HIPCHK(ctx, ivf->s_scnt.ensure((size_t)(B + 2) * 4));  // [B] survivor counts, then nfail and the rescan queue head
+  HIPCHK(ctx, ivf->s_fail.ensure((size_t)B * 4));
+  HIPCHK(ctx, ivf->s_part.ensure((size_t)fpart * 8));
+  HIPCHK(ctx, ivf->s_cnt.ensure((size_t)nlist * 4));
+  HIPCHK(ctx, ivf->s_fill.ensure((size_t)nlist * 4));
+  HIPCHK(ctx, ivf->s_eoff.ensure((size_t)(nlist + 1) * 4));
+  HIPCHK(ctx, ivf->s_ioff.ensure((size_t)(nlist + 1) * 4));
+  HIPCHK(ctx, ivf->s_entries.ensure((size_t)B * np * 8));
+  HIPCHK(ctx, ivf->s_scalars.ensure(kScalarsBytes));
+  uint32_t* scal = ivf->s_scalars.as<uint32_t>();
+  const uint32_t grid = (uint32_t)ctx->num_cus * (uint32_t)std::max(1, wgs_env);
+  const ListTable lists{ivf->t_off.as<uint32_t>(), ivf->t_blocks.as<uint32_t>(), nlist};
+  if (ctx->profiling) (void)hipEventRecord(ivf->sev[3], ctx->stream);
+
+  hipLaunchKernelGGL(prep_queries_kernel, dim3(cdiv(B + 1, 4)), dim3(256), 0, ctx->stream, qpad, B, ivf->dpad,
+                     (_Float16*)ivf->s_qh.p, ivf->s_qn2.as<float>());
+  hipLaunchKernelGGL(first_probe_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, probes, B, np,
+                     ivf->t_len.as<uint32_t>(), 256u, ivf->s_pa.as<uint32_t>());
+  auto plan = [&](const uint32_t* pr, uint32_t n, uint32_t npp, uint32_t sb, unsigned long long* stats) {
+    (void)hipMemsetAsync(ivf->s_cnt.p, 0, (size_t)nlist * 4, ctx->stream);
+    hipLaunchKernelGGL(plan_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, pr, n, ivf->s_cnt.as<uint32_t>());
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ivf->s_cnt.as<uint32_t>(), lists.off,
+                       ivf->t_len.as<uint32_t>(), nlist, sb, Q, ivf->s_eoff.as<uint32_t>(), ivf->s_ioff.as<uint32_t>(),
+                       ivf->s_fill.as<uint32_t>(), scal + 2, scal + 3, stats);
+    hipLaunchKernelGGL(plan_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, pr, n, npp,
+                       ivf->s_eoff.as<uint32_t>(), ivf->s_fill.as<uint32_t>(), ivf->s_entries.as<uint2>());
+  };
+  MfmaScanArgs a{};
+  const bool half_rows = ivf->f16 || ivf->pool.half != nullptr;  // the filter reads fp16 rows (stored or mirrored)
+  const int x_rounded = ivf->f16 ? 0 : (ivf->pool.half ? 1 : 2);  // vs the rows the reference sees: exact, RNE, RTZ
+  a.pool_data = ivf->pool.half ? ivf->pool.half : ivf->pool.data;
+  a.pool_valid = ivf->pool.valid;
+  a.pool_norms = ivf->pool.norms;
+  a.d4 = ivf->d4;
+  a.list_off = lists.off;
+  a.list_blocks = lists.blocks;
+  a.nlist = nlist;
+  a.entry_off = ivf->s_eoff.as<uint32_t>();
+  a.item_off = ivf->s_ioff.as<uint32_t>();
+  a.entries = (const u32x2*)ivf->s_entries.p;
+  a.n_items = scal + 2;
+  a.head = scal + 3;
+  a.qh = (const _Float16*)ivf->s_qh.p;
+  a.zero_row = B;
+  a.dpad = ivf->dpad;
+  a.thr = ivf->s_thr.as<float>();
+  a.cmax = cmax;
+  a.surv = (u32x2*)ivf->s_surv.p;
+  a.sval = ivf->s_sdist.as<float>();
+  a.scnt = ivf->s_scnt.as<uint32_t>();
+  a.slots = ivf->s_mslots.as<uint32_t>();
+  a.capA = (uint32_t)std::max(1, capA_env);
+
+  // A. threshold: MFMA pass over the first segment of a near list -> (k+6)-th smallest v -> thr
+  HIPCHK(ctx, hipMemsetAsync(ivf->s_mslots.p, 0xFF, (size_t)B * 64 * 4, ctx->stream));
+  plan(ivf->s_pa.as<uint32_t>(), B, 1, segbA, nullptr);
+  a.segb = segbA;
+  launch_mfma<1>(ctx, a, M, half_rows, grid);
+  hipLaunchKernelGGL(threshold_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, ivf->s_mslots.as<uint32_t>(),
+                     ivf->s_pa.as<uint32_t>(), ivf->s_qn2.as<float>(), ivf->d_xmax.as<uint32_t>(), B, ka, ivf->dpad,
+                     x_rounded, ivf->s_thr.as<float>());
+
+  // B. filter over all probed lists
+  HIPCHK(ctx, hipMemsetAsync(ivf->s_scnt.p, 0, (size_t)(B + 2) * 4, ctx->stream));
+  plan(probes, B * np, np, segb, (unsigned long long*)(scal + 4));
+  a.segb = segb;
+  launch_mfma<0>(ctx, a, M, half_rows, grid);
+  if (ctx->profiling) (void)hipEventRecord(ivf->sev[4], ctx->stream);
+
+  // C. select
+  VerifyArgs v{};
+  v.pool = ivf->pool.view();
+  v.lists = lists;
+  v.probes = probes;
+  v.glob_blocks = ivf->t_glob.as<uint32_t>();
+  v.queries = qpad;
+  v.qn = ivf->s_qn2.as<float>();
+  v.xmax_bits = ivf->d_xmax.as<uint32_t>();
+  v.thr = ivf->s_thr.as<float>();
+  v.surv = (const u32x2*)ivf->s_surv.p;
+  v.sval = ivf->s_sdist.as<float>();
+  v.scnt = ivf->s_scnt.as<uint32_t>();
+  v.B = B;
+  v.k = k;
+  v.ka = ka;
+  v.nprobe = np;
+  v.d = ivf->dpad;
+  v.dpad = ivf->dpad;
+  v.cmax = cmax;
+  v.rows_f16 = x_rounded;
+  v.out_ids = out_ids;
+  v.out_dist = out_dist;
+  v.out_counts = out_counts;
+  v.out_keys = out_keys;
+  v.fallbacks = ivf->s_fallbacks.as<uint32_t>() + 1;
+  v.fail_list = ivf->s_fail.as<uint32_t>();
+  v.nfail = ivf->s_scnt.as<uint32_t>() + B;
+  if (ivf->f16) hipLaunchKernelGGL((select_kernel<1>), dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, v);
+  else hipLaunchKernelGGL((select_kernel<0>), dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, v);
+
+  // exact rescan of the queries that were not proven (normally none: both kernels return at once)
+  FallbackArgs fa{};
+  fa.pool = ivf->pool.view();
+  fa.lists = lists;
+  fa.probes = probes;
+  fa.queries = qpad;
+  fa.fail_list = v.fail_list;
+  fa.nfail = v.nfail;
+  fa.head = ivf->s_scnt.as<uint32_t>() + B + 1;
+  fa.k = k;
+  fa.nprobe = np;
+  fa.dpad = ivf->dpad;
+  fa.segb = fsegb;
+  fa.maxsegs = fmaxsegs;
+  fa.part = (u32x2*)ivf->s_part.p;
+  if (ivf->f16) hipLaunchKernelGGL((fallback_scan_kernel<1>), dim3(grid), dim3(256), 0, ctx->stream, fa);
+  else hipLaunchKernelGGL((fallback_scan_kernel<0>), dim3(grid), dim3(256), 0, ctx->stream, fa);
+  MergeArgs fm{};
+  fm.pool = ivf->pool.view();
+  fm.lists = lists;
+  fm.probes = probes;
+  fm.glob_blocks = ivf->t_glob.as<uint32_t>();
+  fm.part = ivf->s_part.as<uint2>();
+  fm.B = B;
+  fm.k = k;
+  fm.nprobe = np;
+  fm.maxsegs = fmaxsegs;
+  fm.segb = fsegb;
+  fm.out_ids = out_ids;
+  fm.out_dist = out_dist;
+  fm.out_counts = out_counts;
+  fm.out_keys = out_keys;
+  fm.qlist = v.fail_list;
+  fm.nq = v.nfail;
+  launch_merge(ctx, fm);
   if (ctx->profiling) (void)hipEventRecord(ivf->sev[5], ctx->stream);
   HIPCHK(ctx, hipGetLastError());
   return FVDB_OK;
+}
+
+int run_fine(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t np, const uint32_t* probes,
+             uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys, int role) {
+  static const bool env_exact = getenv("FVDB_SCAN_EXACT") != nullptr;  // tuning aid
+  const bool mfma = ivf->scan_mode == 0 && !env_exact && role == ROLE_LIST && ivf->dpad % 16 == 0 &&
+                    k + kMfmaSlack <= 32 && np <= 256 && B >= 32 && B <= 16384 && ivf->pool.norms != nullptr;
+  if (mfma) return run_fine_mfma(ivf, qpad, B, k, np, probes, out_ids, out_dist, out_counts, out_keys);
+  return run_fine_exact(ivf, qpad, B, k, np, probes, out_ids, out_dist, out_counts, out_keys, role);
 }
 
 int finish_profile(fvdb_ivf* ivf, bool coarse, bool fine) {
@@ -488,7 +711,7 @@ uint32_t sub_batch(fvdb_ivf* ivf, uint32_t B, uint32_t k, uint32_t np) {
   const uint64_t per_q = (uint64_t)np * std::max<uint32_t>(1, cdiv(ivf->max_list_blocks, segb)) * k * 8;
   uint64_t fit = (1ull << 30) / std::max<uint64_t>(per_q, 1);
   fit = std::max<uint64_t>(fit, 1);
-  fit = std::min<uint64_t>(fit, 65536);
+  fit = std::min<uint64_t>(fit, 16384);
   return (uint32_t)std::min<uint64_t>(fit, B);
 }
 
@@ -646,6 +869,8 @@ int fvdb_ivf_create_ex(fvdb_ctx* ctx, uint32_t d, uint32_t nlist, int row_dtype,
   ivf->list_len.assign(nlist, 0);
   ivf->pool.d4 = ivf->d4;
   ivf->pool.esize = ivf->f16 ? 2 : 4;
+  static const bool no_mirror = getenv("FVDB_NO_FP16_MIRROR") != nullptr;  // tuning aid: filter from the f32 rows
+  ivf->pool.mirror = !ivf->f16 && ivf->dpad % 16 == 0 && !no_mirror;
   ivf->cpool.d4 = ivf->d4;
   for (auto& e : ivf->sev) (void)hipEventCreate(&e);
   *out = ivf;
@@ -658,7 +883,8 @@ void fvdb_ivf_destroy(fvdb_ivf* ivf) {
   (void)hipStreamSynchronize(ivf->ctx->stream);
   ivf->pool.release();
   ivf->cpool.release();
-  DBuf* bufs[] = {&ivf->d_cent_pad, &ivf->d_cnorm, &ivf->d_cnmax, &ivf->s_qnorm, &ivf->s_A, &ivf->s_fallbacks,
+  DBuf* bufs[] = {&ivf->d_xmax, &ivf->s_qh, &ivf->s_qn2, &ivf->s_thr, &ivf->s_tA, &ivf->s_pa, &ivf->s_surv, &ivf->s_scnt, &ivf->s_fail, &ivf->s_mslots, &ivf->s_sdist,
+                  &ivf->d_cent_pad, &ivf->d_cnorm, &ivf->d_cnmax, &ivf->s_qnorm, &ivf->s_A, &ivf->s_fallbacks,
                   &ivf->d_centroids_rm, &ivf->c_off, &ivf->c_blocks, &ivf->c_glob, &ivf->t_off, &ivf->t_blocks,
                   &ivf->t_glob, &ivf->t_len, &ivf->s_q, &ivf->s_cpart, &ivf->s_probes, &ivf->s_cnt, &ivf->s_fill, &ivf->s_eoff,
                   &ivf->s_ioff, &ivf->s_entries, &ivf->s_part, &ivf->s_scalars, &ivf->s_ceoff, &ivf->s_cioff,
@@ -691,7 +917,7 @@ static int install_centroids(fvdb_ivf* ivf, const float* d_rowmajor /* device [n
   const uint64_t threads = (uint64_t)nlist * ivf->d4;
   hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, ctx->stream, d_rowmajor, ivf->d,
                      ivf->d4, (uint64_t)nlist, ivf->s_slots.as<uint32_t>(), (const uint64_t*)nullptr,
-                     (float4*)ivf->cpool.data, ivf->cpool.ids, (unsigned long long*)ivf->cpool.valid);
+                     (float4*)ivf->cpool.data, ivf->cpool.ids, (unsigned long long*)ivf->cpool.valid, (void*)nullptr);
   // matrix-core coarse stage: padded row-major table, |c|^2, max |c|^2
   const float* cpad = d_rowmajor;
   if (ivf->d != ivf->dpad) {
@@ -703,12 +929,12 @@ static int install_centroids(fvdb_ivf* ivf, const float* d_rowmajor /* device [n
   }
   HIPCHK(ctx, ivf->d_cnorm.ensure((size_t)nlist * 4));
   HIPCHK(ctx, ivf->d_cnmax.ensure(4));
-  HIPCHK(ctx, ivf->s_fallbacks.ensure(4));
+  HIPCHK(ctx, ivf->s_fallbacks.ensure(8));  // [0] coarse, [1] list scan
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(nlist, 256)), dim3(256), 0, ctx->stream, cpad, ivf->dpad, ivf->dpad,
                      nlist, ivf->d_cnorm.as<float>());
   hipLaunchKernelGGL(max_f32_kernel, dim3(1), dim3(64), 0, ctx->stream, ivf->d_cnorm.as<float>(), nlist,
                      ivf->d_cnmax.as<float>());
-  HIPCHK(ctx, hipMemsetAsync(ivf->s_fallbacks.p, 0, 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ivf->s_fallbacks.p, 0, 8, ctx->stream));
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ivf->trained = true;
@@ -848,8 +1074,14 @@ static int append_staged(fvdb_ivf* ivf, const uint64_t* ids, uint64_t n, const u
     const uint64_t threads = n * ivf->d4;
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, ctx->stream, ivf->s_in.as<float>(),
                        ivf->d, ivf->d4, n, ivf->s_slots.as<uint32_t>(), ids ? ivf->s_ids.as<uint64_t>() : nullptr,
-                       (float4*)ivf->pool.data, ivf->pool.ids, (unsigned long long*)ivf->pool.valid);
+                       (float4*)ivf->pool.data, ivf->pool.ids, (unsigned long long*)ivf->pool.valid, ivf->pool.half);
   }
+  if (!ivf->d_xmax.p) {
+    HIPCHK(ctx, ivf->d_xmax.ensure(4));
+    HIPCHK(ctx, hipMemsetAsync(ivf->d_xmax.p, 0, 4, ctx->stream));
+  }
+  hipLaunchKernelGGL(pool_row_norms_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, ivf->s_in.as<float>(), ivf->d, n,
+                     ivf->f16 ? 1 : 0, ivf->s_slots.as<uint32_t>(), ivf->pool.norms, ivf->d_xmax.as<uint32_t>());
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FVDB_OK;
@@ -1017,6 +1249,34 @@ int fvdb_ivf_set_coarse_mode(fvdb_ivf* ivf, int mode) {
   if (!ivf) return FVDB_E_INVALID;
   if (mode != FVDB_COARSE_AUTO && mode != FVDB_COARSE_EXACT) FAIL(ivf->ctx, FVDB_E_INVALID, "unknown coarse mode");
   ivf->coarse_mode = mode;
+  return FVDB_OK;
+}
+
+int fvdb_ivf_set_scan_mode(fvdb_ivf* ivf, int mode) {
+  if (!ivf) return FVDB_E_INVALID;
+  if (mode != FVDB_SCAN_AUTO && mode != FVDB_SCAN_EXACT) FAIL(ivf->ctx, FVDB_E_INVALID, "unknown scan mode");
+  ivf->scan_mode = mode;
+  return FVDB_OK;
+}
+
+int fvdb_ivf_scan_survivors(fvdb_ivf* ivf, uint32_t* out, uint32_t B) {
+  fvdb_ctx* ctx = ivf->ctx;
+  if (!ivf->s_scnt.p || ivf->s_scnt.cap < (size_t)B * 4) FAIL(ctx, FVDB_E_INVALID, "no matrix-core scan of that size has run");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpyAsync(out, ivf->s_scnt.p, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+
+int fvdb_ivf_scan_fallbacks(fvdb_ivf* ivf, uint64_t* out) {
+  fvdb_ctx* ctx = ivf->ctx;
+  *out = 0;
+  if (!ivf->s_fallbacks.p) return FVDB_OK;
+  uint32_t v = 0;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpyAsync(&v, ivf->s_fallbacks.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *out = v;
   return FVDB_OK;
 }
 

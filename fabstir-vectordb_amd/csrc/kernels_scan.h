@@ -329,14 +329,19 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(
 template <int KR>
 __global__ __launch_bounds__(256) void merge_topk_kernel(const MergeArgs m) {
   const int lane = threadIdx.x & 63;
-  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= m.B) return;
+  if (m.qlist) {
+    if (q >= *m.nq) return;
+    q = m.qlist[q];
+  }
   WaveTopK<KR> tk;
   tk.init();
   uint32_t th = kInf32, tl = kInf32;
   uint32_t base = 0;
   for (uint32_t r = 0; r < m.nprobe; ++r) {
     const uint32_t L = m.probes ? m.probes[q * m.nprobe + r] : 0u;
+    if (L == kInf32) continue;  // "no list" filler
     const uint32_t nblk = m.lists.off[L + 1] - m.lists.off[L];
     const uint32_t nseg = (nblk + m.segb - 1) / m.segb;
     for (uint32_t s = 0; s < nseg; ++s) {
@@ -368,6 +373,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const MergeArgs m) {
         uint32_t b2 = 0, L = 0;
         for (uint32_t r = 0; r < m.nprobe; ++r) {  // wave-uniform walk, per-lane pick
           const uint32_t Lr = m.probes ? m.probes[q * m.nprobe + r] : 0u;
+          if (Lr == kInf32) continue;
           const uint32_t nb = m.glob_blocks[Lr] * 64;
           if (klo >= b2 && klo - b2 < nb) {
             L = Lr;

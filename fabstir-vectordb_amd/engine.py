@@ -298,6 +298,20 @@ class DeviceIVF:
         self.ctx.check(self.lib.fvdb_ivf_coarse_fallbacks(self.h, C.byref(v)))
         return int(v.value)
 
+    def set_scan_mode(self, mode):
+        """0 = fp16 MFMA filter + exact verification (default), 1 = exact scan of every probed row."""
+        self.ctx.check(self.lib.fvdb_ivf_set_scan_mode(self.h, int(mode)))
+
+    def scan_fallbacks(self):
+        v = C.c_uint64(0)
+        self.ctx.check(self.lib.fvdb_ivf_scan_fallbacks(self.h, C.byref(v)))
+        return int(v.value)
+
+    def scan_survivors(self, B):
+        out = np.empty(B, np.uint32)
+        self.ctx.check(self.lib.fvdb_ivf_scan_survivors(self.h, _ptr(out, u32p), B))
+        return out
+
     def last_stats(self):
         st = _capi.SearchStats()
         self.ctx.check(self.lib.fvdb_ivf_last_stats(self.h, C.byref(st)))

@@ -167,6 +167,22 @@ int fvdb_ivf_set_coarse_mode(fvdb_ivf* ivf, int mode);
 /* Queries (since the centroids were installed) whose proposal could not be proven and were ranked exactly. */
 int fvdb_ivf_coarse_fallbacks(fvdb_ivf* ivf, uint64_t* out);
 
+/* Inverted-list scan implementation.  FVDB_SCAN_AUTO (default): fp16 MFMA evaluates |x|^2 - 2 x.q for every
+ * (row, query) of the probed lists and discards the rows that provably cannot reach the top k (threshold from an
+ * exact scan of the query's nearest lists plus a rounding-error bound); the few survivors are scored with the
+ * reference's sequential f32 fold and selected by (distance, scan position).  A query whose k-th result is not
+ * strictly below its threshold is rescanned exactly.  Results are identical to FVDB_SCAN_EXACT (every probed
+ * row scored with the reference's arithmetic) by construction.  AUTO applies when padded d % 16 == 0,
+ * k <= 26, nprobe <= 256 and the batch has 32..16384 queries; other shapes use the exact scan. */
+#define FVDB_SCAN_AUTO 0
+#define FVDB_SCAN_EXACT 1
+int fvdb_ivf_set_scan_mode(fvdb_ivf* ivf, int mode);
+/* Queries (since the centroids were installed) that were rescanned exactly. */
+int fvdb_ivf_scan_fallbacks(fvdb_ivf* ivf, uint64_t* out);
+
+/* Diagnostic: rows per query that survived the matrix-core filter in the last (sub-)batch of B queries. */
+int fvdb_ivf_scan_survivors(fvdb_ivf* ivf, uint32_t* out, uint32_t B);
+
 /* Counters of the last search on this index (for roofline accounting). */
 typedef struct fvdb_search_stats {
   uint64_t rows_scanned;      /* sum over queries of rows in probed lists (algorithmic) */
