@@ -87,6 +87,7 @@ SIGNATURES = {
     "fvdb_graph_upload": (i32, [vp, u32, u32p, C.POINTER(C.c_uint8), u32p, u32p, u32]),
     "fvdb_graph_set_deleted": (i32, [vp, u32, i32]),
     "fvdb_graph_search_dev": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp]),
+    "fvdb_graph_kernel_times": (i32, [vp, f32p, u32p]),
     "fvdb_scorer_launch": (i32, [vp, u32, u32]),
     "fvdb_scorer_wait": (i32, [vp]),
 }

@@ -204,10 +204,12 @@ struct fvdb_ivf {
   DBuf s_q, s_cpart, s_probes, s_cnt, s_fill, s_eoff, s_ioff, s_entries, s_part, s_scalars, s_ceoff, s_cioff;
   DBuf s_in, s_slots, s_ids, s_clusters, s_out_ids, s_out_dist, s_out_cnt, s_cdist;
   fvdb_search_stats last_stats{};
-  float stage_ms[5] = {0, 0, 0, 0, 0};  // coarse scan, coarse merge, plan, fine scan, fine merge
+  // coarse scan, coarse merge, plan, fine scan, fine merge, [5] the matrix-core filter kernel alone (inside fine scan)
+  float stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool pend_filter = false;
   bool pending_profile = false, pend_coarse = false, pend_fine = false, collecting = false;
   uint64_t stage_calls = 0;
-  hipEvent_t sev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t sev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 struct fvdb_store {
@@ -226,6 +228,10 @@ struct fvdb_graph {
   DBuf s_q, s_visited, s_touched;
   uint32_t vis_B = 0, vis_words = 0, vis_tcap = 0;
   bool uploaded = false;
+  // profiling: HIP events around the last launches of the traversal kernel (ring of 64)
+  hipEvent_t kev[64][2] = {};
+  uint32_t kev_n = 0;   // launches recorded since the last fvdb_graph_kernel_times call
+  uint64_t last_rows = 0;
 };
 
 struct fvdb_scorer {
@@ -591,8 +597,11 @@ int run_fine_mfma(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint
   HIPCHK(ctx, hipMemsetAsync(ivf->s_scnt.p, 0, (size_t)(B + 2) * 4, ctx->stream));
   plan(probes, B * np, np, segb, (unsigned long long*)(scal + 4));
   a.segb = segb;
+  if (ctx->profiling) (void)hipEventRecord(ivf->sev[6], ctx->stream);
   launch_mfma<0>(ctx, a, M, half_rows, grid);
+  if (ctx->profiling) (void)hipEventRecord(ivf->sev[7], ctx->stream);
   if (ctx->profiling) (void)hipEventRecord(ivf->sev[4], ctx->stream);
+  ivf->pend_filter = true;
 
   // C. select
   VerifyArgs v{};
@@ -668,6 +677,7 @@ int run_fine_mfma(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint
 int run_fine(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t np, const uint32_t* probes,
              uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys, int role) {
   static const bool env_exact = getenv("FVDB_SCAN_EXACT") != nullptr;  // tuning aid
+  ivf->pend_filter = false;
   const bool mfma = ivf->scan_mode == 0 && !env_exact && role == ROLE_LIST && ivf->dpad % 16 == 0 &&
                     k + kMfmaSlack <= 32 && np <= 256 && B >= 32 && B <= 16384 && ivf->pool.norms != nullptr;
   if (mfma) return run_fine_mfma(ivf, qpad, B, k, np, probes, out_ids, out_dist, out_counts, out_keys);
@@ -700,6 +710,10 @@ int finish_profile(fvdb_ivf* ivf, bool coarse, bool fine) {
     ivf->stage_ms[3] += ms;
     (void)hipEventElapsedTime(&ms, ivf->sev[4], ivf->sev[5]);
     ivf->stage_ms[4] += ms;
+    if (ivf->pend_filter) {
+      (void)hipEventElapsedTime(&ms, ivf->sev[6], ivf->sev[7]);
+      ivf->stage_ms[5] += ms;
+    }
   }
   ivf->stage_calls += 1;
   return FVDB_OK;
@@ -1319,7 +1333,7 @@ int fvdb_ivf_profile_collect(fvdb_ivf* ivf) {
 // stage times accumulated while profiling is on: ms[5] = coarse scan, coarse merge, plan, fine scan,
 // fine merge; returns the number of searches accumulated and resets.
 uint64_t fvdb_ivf_stage_times(fvdb_ivf* ivf, float* ms_out) {
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < 8; ++i) {
     ms_out[i] = ivf->stage_ms[i];
     ivf->stage_ms[i] = 0;
   }
@@ -1725,6 +1739,10 @@ int fvdb_graph_create(fvdb_store* s, fvdb_graph** out) {
 }
 
 void fvdb_graph_destroy(fvdb_graph* g) {
+  if (g)
+    for (auto& e : g->kev)
+      for (auto& x : e)
+        if (x) (void)hipEventDestroy(x);
   if (!g) return;
   (void)hipSetDevice(g->store->ctx->device);
   (void)hipStreamSynchronize(g->store->ctx->stream);
@@ -1839,10 +1857,42 @@ int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_
             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
   }
 #endif
+  hipEvent_t* ev = nullptr;
+  if (ctx->profiling) {
+    ev = g->kev[g->kev_n & 63];
+    if (!ev[0]) {
+      (void)hipEventCreate(&ev[0]);
+      (void)hipEventCreate(&ev[1]);
+    }
+    (void)hipEventRecord(ev[0], ctx->stream);
+  }
   hipLaunchKernelGGL(hnsw_search_kernel, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
                      g->s_visited.as<uint32_t>(), words, g->s_touched.as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
                      out_counts_dev, out_status_dev);
+  if (ev) {
+    (void)hipEventRecord(ev[1], ctx->stream);
+    g->kev_n += 1;
+  }
   HIPCHK(ctx, hipGetLastError());
+  return FVDB_OK;
+}
+
+int fvdb_graph_kernel_times(fvdb_graph* g, float* ms_sum, uint32_t* launches) {
+  fvdb_ctx* ctx = g->store->ctx;
+  *ms_sum = 0.0f;
+  *launches = 0;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t n = std::min<uint32_t>(g->kev_n, 64);
+  for (uint32_t i = 0; i < n; ++i) {
+    hipEvent_t* ev = g->kev[(g->kev_n - 1 - i) & 63];
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) {
+      *ms_sum += ms;
+      *launches += 1;
+    }
+  }
+  g->kev_n = 0;
   return FVDB_OK;
 }
 

@@ -12,6 +12,7 @@
 // (tests/test_gpu_host_mirror.py::test_device_traversal_*).
 #pragma once
 #include "common.h"
+#include "kernels_scan.h"
 
 #pragma clang fp contract(off)
 
@@ -89,113 +90,100 @@ __device__ __forceinline__ HItem h_pop(HItem* h, uint32_t& n) {
   return item;
 }
 
-constexpr int kTileRows = 16;
-constexpr int kRowsInFlight = 8;
-
-// distances of the wave's query (in LDS) to `np` rows listed in pending[], into pdist[]
-__device__ __forceinline__ void score_pending(const GraphView& g, const float* __restrict__ q_lds, float* tile,
+// Distances of the wave's query to the `np` (<= 64) rows listed in pending[], into pdist[]: one lane per row,
+// the reference's left-to-right f32 fold (src/hnsw/core.rs:691-697).
+//
+// A lone wave per SIMD has nothing to hide HBM latency behind, and a lane's fold consumes its row strictly in
+// order, so the rows are first pulled towards the core all at once: every 128-byte line of every row is touched
+// by one `global_load_lds_dword` (data discarded into an LDS scratch word per lane, no VGPR held), np*12 loads in
+// flight together.  Each lane then streams its own row (row-major, 16 bytes per load, 32 dims per batch, two
+// batches in flight) out of L2; the query sits in LDS and is read with broadcast loads one batch ahead.
+__device__ __forceinline__ void score_pending(const GraphView& g, const float* q_lds, float* pf_scratch,
                                               const uint32_t* pending, float* pdist, uint32_t np, int lane) {
-  const uint32_t dpad = g.dpad, d4 = dpad >> 2, S = dpad + 1;  // odd row stride: lanes hit distinct banks
-  for (uint32_t t0 = 0; t0 < np; t0 += kTileRows) {
-    const uint32_t rows = min((uint32_t)kTileRows, np - t0);
-#ifndef FVDB_GRAPH_REP_LOAD
-#define FVDB_GRAPH_REP_LOAD 1
-#endif
-    // coalesced row loads (1 KiB per wave-instruction), kRowsInFlight rows per round trip
-    for (int repl = 0; repl < FVDB_GRAPH_REP_LOAD; ++repl)
-    for (uint32_t r0 = 0; r0 < rows; r0 += kRowsInFlight) {
-      if (repl) asm volatile("" ::: "memory");
-      float4 v[kRowsInFlight][2];
-#pragma unroll
-      for (int rr = 0; rr < kRowsInFlight; ++rr) {
-        const uint32_t r = r0 + rr;
-        if (r < rows) {
-          const float4* src = (const float4*)(g.rows + (size_t)pending[t0 + r] * dpad);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const uint32_t c = lane + 64 * h;
-            if (c < d4) v[rr][h] = src[c];
-          }
-        }
-      }
-#pragma unroll
-      for (int rr = 0; rr < kRowsInFlight; ++rr) {
-        const uint32_t r = r0 + rr;
-        if (r < rows) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const uint32_t c = lane + 64 * h;
-            if (c < d4) {
-              float* dst = tile + r * S + 4 * c;
-              dst[0] = v[rr][h].x;
-              dst[1] = v[rr][h].y;
-              dst[2] = v[rr][h].z;
-              dst[3] = v[rr][h].w;
-            }
-          }
-        }
-      }
-      for (uint32_t c = 128 + lane; c < d4; c += 64) {  // d > 512: remaining chunks, row by row
-        for (uint32_t r = r0; r < min(r0 + (uint32_t)kRowsInFlight, rows); ++r) {
-          const float4 w = ((const float4*)(g.rows + (size_t)pending[t0 + r] * dpad))[c];
-          float* dst = tile + r * S + 4 * c;
-          dst[0] = w.x;
-          dst[1] = w.y;
-          dst[2] = w.z;
-          dst[3] = w.w;
-        }
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0);  // the wave's LDS writes land before its reads
-    __builtin_amdgcn_wave_barrier();
-#ifndef FVDB_GRAPH_REP_DIST
-#define FVDB_GRAPH_REP_DIST 1
-#endif
-    for (int rep = 0; rep < FVDB_GRAPH_REP_DIST; ++rep)
-    if ((uint32_t)lane < rows) {  // one lane per row: the reference's left-to-right f32 fold
-      const float* x = tile + lane * S;
-      float acc = 0.0f;
-      if (rep) asm volatile("" ::: "memory");
-      uint32_t j = 0;
-      // 32 dims per step: all LDS reads of a step are issued before its arithmetic starts (a lone wave
-      // per SIMD has nothing else to hide the ~100-cycle LDS latency behind)
-      for (; j + 32 <= dpad; j += 32) {
-        float xv[32];
-        float4 qv[8];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) xv[i] = x[j + i];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) qv[i] = *(const float4*)(q_lds + j + 4 * i);  // LDS broadcast
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float t;
-          t = qv[i].x - xv[4 * i + 0]; acc = acc + t * t;
-          t = qv[i].y - xv[4 * i + 1]; acc = acc + t * t;
-          t = qv[i].z - xv[4 * i + 2]; acc = acc + t * t;
-          t = qv[i].w - xv[4 * i + 3]; acc = acc + t * t;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      for (; j < dpad; j += 4) {
-        const float4 qv = *(const float4*)(q_lds + j);
-        float t;
-        t = qv.x - x[j + 0]; acc = acc + t * t;
-        t = qv.y - x[j + 1]; acc = acc + t * t;
-        t = qv.z - x[j + 2]; acc = acc + t * t;
-        t = qv.w - x[j + 3]; acc = acc + t * t;
-      }
-      pdist[t0 + lane] = sqrtf(acc);
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
+  const uint32_t dpad = g.dpad;
+  const uint32_t lpr = (dpad + 31) >> 5, nlines = np * lpr;  // 32 floats per line
+  for (uint32_t l = lane; l < nlines; l += 64) {
+    const uint32_t r = l / lpr, ln = l - r * lpr;
+    const float* src = g.rows + (size_t)pending[r] * dpad + ln * 32;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)pf_scratch, 4, 0, 0);
   }
+  if ((uint32_t)lane < np) {
+    const float* row = g.rows + (size_t)pending[lane] * dpad;
+    const float4* xp = (const float4*)row;
+    const float4* qp = (const float4*)q_lds;  // same address in every lane: LDS broadcast reads
+    const uint32_t nb = dpad >> 5;            // whole 32-dim batches
+    float acc = 0.0f;
+    auto issue = [&](uint32_t bi, float4 (&dst)[8]) {
+      const uint32_t bb = bi < nb ? bi : nb - 1;  // past the end: re-request the last batch (keeps counts static)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dst[i] = xp[bb * 8 + i];
+    };
+    auto issue_q = [&](uint32_t bi, float4 (&dst)[8]) {
+      const uint32_t bb = bi < nb ? bi : nb - 1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dst[i] = qp[bb * 8 + i];
+    };
+    auto fold = [&](const float4 (&src)[8], const float4 (&qv)[8]) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float t;
+        t = qv[i].x - src[i].x; acc = acc + t * t;
+        t = qv[i].y - src[i].y; acc = acc + t * t;
+        t = qv[i].z - src[i].z; acc = acc + t * t;
+        t = qv[i].w - src[i].w; acc = acc + t * t;
+      }
+    };
+    uint32_t done = 0;
+    if (nb >= 6) {
+      // rows two batches ahead, query one batch ahead; six batches per trip so every buffer index is static
+      float4 r0[8], r1[8], r2[8], qa[8], qb[8];
+      const uint32_t nb6 = nb - nb % 6;
+      issue(0, r0);
+      issue(1, r1);
+      issue_q(0, qa);
+      for (uint32_t bi = 0; bi < nb6; bi += 6) {
+#define FVDB_STEP(K, RC, RN, QC, QN)              \
+  issue(bi + (K) + 2, RN);                        \
+  issue_q(bi + (K) + 1, QN);                      \
+  __builtin_amdgcn_sched_barrier(0);              \
+  fold(RC, QC);                                   \
+  __builtin_amdgcn_sched_barrier(0)
+        FVDB_STEP(0, r0, r2, qa, qb);
+        FVDB_STEP(1, r1, r0, qb, qa);
+        FVDB_STEP(2, r2, r1, qa, qb);
+        FVDB_STEP(3, r0, r2, qb, qa);
+        FVDB_STEP(4, r1, r0, qa, qb);
+        FVDB_STEP(5, r2, r1, qb, qa);
+#undef FVDB_STEP
+      }
+      done = nb6;
+    }
+    for (uint32_t bi = done; bi < nb; ++bi) {
+      float4 t8[8], q8[8];
+      issue(bi, t8);
+      issue_q(bi, q8);
+      fold(t8, q8);
+    }
+    for (uint32_t j = nb << 5; j < dpad; j += 4) {
+      const float4 xv = *(const float4*)(row + j);
+      const float4 qv = *(const float4*)(q_lds + j);
+      float t;
+      t = qv.x - xv.x; acc = acc + t * t;
+      t = qv.y - xv.y; acc = acc + t * t;
+      t = qv.z - xv.z; acc = acc + t * t;
+      t = qv.w - xv.w; acc = acc + t * t;
+    }
+    pdist[lane] = sqrtf(acc);
+  }
+  __builtin_amdgcn_s_waitcnt(0);  // distances (and the discarded prefetch words) have landed in LDS
+  __builtin_amdgcn_wave_barrier();
 }
 
-// LDS carve-up per wave (bytes): q [dpad*4] | tile [16*(dpad+1)*4] | pending [64*4] | pdist [64*4] |
-// scalars [16*4] | near [(ef+1)*8] | res [ef*8] | cand [cand_cap*8]
+// LDS carve-up per wave (bytes): q [dpad*4] | prefetch scratch [64*4] | pending [64*4] | pdist [64*4] |
+// scalars [16*4] | near [(ef+2)*8] | res [(ef+1)*8] | cand [cand_cap*8]
 __host__ __device__ inline size_t graph_lds_bytes(uint32_t dpad, uint32_t ef, uint32_t cand_cap) {
-  size_t b = (size_t)dpad * 4 + (size_t)kTileRows * (dpad + 1) * 4 + 64 * 4 + 64 * 4 + 16 * 4;
+  size_t b = (size_t)dpad * 4 + 64 * 4 + 64 * 4 + 64 * 4 + 16 * 4;
   b = (b + 7) & ~(size_t)7;
   b += (size_t)(ef + 2) * 8 + (size_t)(ef + 1) * 8 + (size_t)cand_cap * 8;
   return (b + 15) & ~(size_t)15;
@@ -214,8 +202,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   if (b >= B) return;
   const uint32_t dpad = g.dpad;
   float* q_lds = (float*)lds;
-  float* tile = q_lds + dpad;
-  uint32_t* pending = (uint32_t*)(tile + kTileRows * (dpad + 1));
+  float* pf_scratch = q_lds + dpad;
+  uint32_t* pending = (uint32_t*)(pf_scratch + 64);
   float* pdist = (float*)(pending + 64);
   uint32_t* sc = (uint32_t*)(pdist + 64);  // [0] stop, [1] node, [2] status, [3] nN
   size_t off = ((size_t)((unsigned char*)(sc + 16) - lds) + 7) & ~(size_t)7;
@@ -234,7 +222,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   if (lane == 0) pending[0] = g.entry;
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
-  score_pending(g, q_lds, tile, pending, pdist, 1, lane);
+  score_pending(g, q_lds, pf_scratch, pending, pdist, 1, lane);
   uint32_t n_res = 1;
   if (lane == 0) res[0] = HItem{g.entry, pdist[0]};
   __builtin_amdgcn_s_waitcnt(0);
@@ -315,7 +303,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       STAMP(t2s);
       STAMP_ADD(1, t1s, t2s);
       if (np) {
-        score_pending(g, q_lds, tile, pending, pdist, np, lane);
+        score_pending(g, q_lds, pf_scratch, pending, pdist, np, lane);
         STAMP(t3s);
         STAMP_ADD(2, t2s, t3s);
 #ifdef FVDB_GRAPH_STAMPS

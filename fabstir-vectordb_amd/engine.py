@@ -318,9 +318,9 @@ class DeviceIVF:
         return dict(rows_scanned=st.rows_scanned, work_items=st.work_items, list_rows_touched=st.list_rows_touched)
 
     def stage_times(self):
-        ms = np.zeros(5, np.float32)
+        ms = np.zeros(8, np.float32)
         n = self.lib.fvdb_ivf_stage_times(self.h, _ptr(ms, f32p))
-        return int(n), dict(zip(("coarse_scan", "coarse_merge", "plan", "fine_scan", "fine_merge"), ms.tolist()))
+        return int(n), dict(zip(("coarse_scan", "coarse_merge", "plan", "fine_scan", "fine_merge", "mfma_filter_kernel"), ms.tolist()))
 
 
 class RowStore:

@@ -111,6 +111,9 @@ void fvh_hnsw_set_threads(void* p, int t) { ((HNSWIndex*)p)->set_threads(t); }
 void fvh_hnsw_set_device_traversal(void* p, int on) { ((HNSWIndex*)p)->set_device_traversal(on != 0); }
 int fvh_hnsw_device_traversal(void* p) { return ((HNSWIndex*)p)->device_traversal(); }
 uint64_t fvh_hnsw_device_fallbacks(void* p) { return ((HNSWIndex*)p)->device_fallbacks(); }
+int fvh_hnsw_graph_kernel_times(void* p, float* ms_sum, uint32_t* launches) {
+  return ((HNSWIndex*)p)->graph_kernel_times(ms_sum, launches);
+}
 uint32_t fvh_hnsw_dimension(void* p) { return ((HNSWIndex*)p)->dimension(); }
 
 // ---- HybridIndex ----

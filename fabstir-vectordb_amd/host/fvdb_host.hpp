@@ -169,6 +169,12 @@ class HNSWIndex {
   void set_device_traversal(bool on) { device_traversal_ = on; }
   bool device_traversal() const { return device_traversal_; }
   uint64_t device_fallbacks() const { return n_fallback_; }
+  // profiling on: summed HIP-event duration of the traversal kernel's launches since the last call
+  int graph_kernel_times(float* ms_sum, uint32_t* launches) {
+    *ms_sum = 0.0f;
+    *launches = 0;
+    return graph_ ? fvdb_graph_kernel_times(graph_, ms_sum, launches) : 0;
+  }
 
  private:
   struct Query {

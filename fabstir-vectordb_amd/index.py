@@ -66,6 +66,7 @@ HOST_SIGNATURES = {
     "fvh_hnsw_set_device_traversal": (None, [vp, i32]),
     "fvh_hnsw_device_traversal": (i32, [vp]),
     "fvh_hnsw_device_fallbacks": (u64, [vp]),
+    "fvh_hnsw_graph_kernel_times": (i32, [vp, f32p, u32p]),
     "fvh_hybrid_new": (vp, [vp, vp, dbl, u64, i32, u64, u32, u32, u32, u64, u32, u32, u32, u32, u64]),
     "fvh_hybrid_free": (None, [vp]),
     "fvh_hybrid_initialize": (i32, [vp, f32p, u64, u32]),
@@ -253,9 +254,9 @@ class IVFIndex(_Base):
         return out
 
     def stage_times(self):
-        ms = np.zeros(5, np.float32)
+        ms = np.zeros(8, np.float32)
         n = self.ctx.lib.fvdb_ivf_stage_times(self._dev(), _ptr(ms, f32p))
-        return int(n), dict(zip(("coarse_scan", "coarse_merge", "plan", "fine_scan", "fine_merge"), ms.tolist()))
+        return int(n), dict(zip(("coarse_scan", "coarse_merge", "plan", "fine_scan", "fine_merge", "mfma_filter_kernel"), ms.tolist()))
 
     def last_stats(self):
         st = _capi.SearchStats()
@@ -376,6 +377,12 @@ class HNSWIndex(_Base):
 
     def device_fallbacks(self):
         return int(self.lib.fvh_hnsw_device_fallbacks(self.h))
+
+    def graph_kernel_times(self):
+        """(summed ms, launches) of the device traversal kernel since the last call (needs ctx profiling on)."""
+        ms, n = C.c_float(0), C.c_uint32(0)
+        self.lib.fvh_hnsw_graph_kernel_times(self.h, C.byref(ms), C.byref(n))
+        return float(ms.value), int(n.value)
 
 
 class HybridIndex(_Base):

@@ -190,8 +190,9 @@ typedef struct fvdb_search_stats {
   uint64_t list_rows_touched; /* rows of the union of probed lists (physical lower bound) */
 } fvdb_search_stats;
 int fvdb_ivf_last_stats(fvdb_ivf* ivf, fvdb_search_stats* out);
-/* With profiling on: ms[5] = coarse scan, coarse merge, plan, fine scan, fine merge, summed over the
- * searches since the last call; returns how many searches (sub-batches) were accumulated. */
+/* With profiling on: ms[8] = coarse scan, coarse merge, plan, fine scan, fine merge, [5] the matrix-core filter
+ * kernel alone (part of fine scan; 0 on the exact path), [6..7] reserved (0) — summed over the searches since
+ * the last call; returns how many searches (sub-batches) were accumulated. */
 uint64_t fvdb_ivf_stage_times(fvdb_ivf* ivf, float* ms_out);
 int fvdb_ivf_profile_collect(fvdb_ivf* ivf);  /* profiling mode 2: fold the last search's events in */
 
@@ -249,6 +250,9 @@ int fvdb_graph_set_deleted(fvdb_graph* g, uint32_t node, int deleted);
 int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_t k, uint32_t ef,
                           uint32_t* out_nodes_dev, float* out_dist_dev, uint32_t* out_counts_dev,
                           uint32_t* out_status_dev);
+/* With profiling on (fvdb_ctx_set_profiling): summed duration (HIP events on the launch stream) of the last
+ * <= 64 launches of the traversal kernel since the previous call, and how many were summed.  Synchronises. */
+int fvdb_graph_kernel_times(fvdb_graph* g, float* ms_sum, uint32_t* launches);
 
 #ifdef __cplusplus
 }
