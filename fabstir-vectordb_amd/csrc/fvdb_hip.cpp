@@ -229,6 +229,8 @@ struct fvdb_graph {
   uint32_t vis_B = 0, vis_words = 0, vis_tcap = 0;
   bool uploaded = false;
   // profiling: HIP events around the last launches of the traversal kernel (ring of 64)
+  std::vector<uint8_t> h_deleted;  // host copy of the flags: searches skip the per-neighbour flag load when none is set
+  uint64_t n_deleted = 0;
   hipEvent_t kev[64][2] = {};
   uint32_t kev_n = 0;   // launches recorded since the last fvdb_graph_kernel_times call
   uint64_t last_rows = 0;
@@ -1790,6 +1792,13 @@ int fvdb_graph_upload(fvdb_graph* g, uint32_t n, const uint32_t* levels, const u
   HIPCHK(ctx, hipMemcpyAsync(g->d_slot_start.p, slot_start, (size_t)(slots + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
   if (edges) HIPCHK(ctx, hipMemcpyAsync(g->d_adj.p, adj, (size_t)edges * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  g->h_deleted.assign(n, 0);
+  g->n_deleted = 0;
+  for (uint32_t i = 0; i < n; ++i)
+    if (del32[i]) {
+      g->h_deleted[i] = 1;
+      g->n_deleted += 1;
+    }
   g->n = n;
   g->entry = entry_node;
   g->top_level = levels[entry_node];
@@ -1803,6 +1812,10 @@ int fvdb_graph_set_deleted(fvdb_graph* g, uint32_t node, int deleted) {
   fvdb_ctx* ctx = g->store->ctx;
   if (!g->uploaded || node >= g->n) FAIL(ctx, FVDB_E_NOT_FOUND, "no such node");
   const uint32_t v = deleted ? 1u : 0u;
+  if (g->h_deleted[node] != (uint8_t)v) {
+    g->n_deleted += v ? 1 : -1;
+    g->h_deleted[node] = (uint8_t)v;
+  }
   HIPCHK(ctx, hipMemcpyAsync(g->d_deleted.as<uint32_t>() + node, &v, 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FVDB_OK;
@@ -1838,11 +1851,15 @@ int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_
   const uint32_t cand_cap = std::max<uint32_t>(1024, 8 * ef);
   const size_t lds = graph_lds_bytes(s->dpad, ef, cand_cap);
   if (lds > 160 * 1024) FAIL(ctx, FVDB_E_UNSUPPORTED, "dimension / ef too large for the on-chip traversal state");
-  if (lds > 48 * 1024)
-    HIPCHK(ctx, hipFuncSetAttribute((const void*)hnsw_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static const bool lds_heaps = getenv("FVDB_GRAPH_LDS_HEAPS") != nullptr;  // tuning aid: lane-0 heaps for any ef
+  const bool rh = ef <= 63 && !lds_heaps;
+  if (lds > 48 * 1024) {
+    if (rh) HIPCHK(ctx, hipFuncSetAttribute((const void*)hnsw_search_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else HIPCHK(ctx, hipFuncSetAttribute((const void*)hnsw_search_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   GraphView gv{s->data, g->d_level.as<uint32_t>(), g->d_deleted.as<uint32_t>(), g->d_slot_of.as<uint32_t>(),
                g->d_slot_start.as<uint32_t>(), g->d_adj.as<uint32_t>(), g->d_adj0.as<uint32_t>(), g->stride0, g->n,
-               s->dpad, g->entry, g->top_level, nullptr};
+               s->dpad, g->entry, g->top_level, g->n_deleted ? 1u : 0u, nullptr};
 #ifdef FVDB_GRAPH_STAMPS
   static unsigned long long* d_stamps = nullptr;
   if (!d_stamps) {
@@ -1866,9 +1883,14 @@ int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_
     }
     (void)hipEventRecord(ev[0], ctx->stream);
   }
-  hipLaunchKernelGGL(hnsw_search_kernel, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
-                     g->s_visited.as<uint32_t>(), words, g->s_touched.as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
-                     out_counts_dev, out_status_dev);
+  if (rh)
+    hipLaunchKernelGGL(hnsw_search_kernel<true>, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
+                       g->s_visited.as<uint32_t>(), words, g->s_touched.as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
+                       out_counts_dev, out_status_dev);
+  else
+    hipLaunchKernelGGL(hnsw_search_kernel<false>, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
+                       g->s_visited.as<uint32_t>(), words, g->s_touched.as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
+                       out_counts_dev, out_status_dev);
   if (ev) {
     (void)hipEventRecord(ev[1], ctx->stream);
     g->kev_n += 1;

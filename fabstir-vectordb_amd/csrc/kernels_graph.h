@@ -28,6 +28,7 @@ struct GraphView {
   const uint32_t* adj0;       // layer 0 again, fixed stride: adj0[node*stride0] = count, then the neighbours
   uint32_t stride0;           //   (one dependent load instead of three on the layer that takes ~all hops)
   uint32_t n, dpad, entry, top_level;
+  uint32_t any_deleted;       // 0: no node is flagged, the per-neighbour flag load is skipped
   unsigned long long* stamps;  // diagnostic builds only (FVDB_GRAPH_STAMPS): per-phase cycle sums
 };
 
@@ -88,6 +89,144 @@ __device__ __forceinline__ HItem h_pop(HItem* h, uint32_t& n) {
     h_sift_up(h, 0, pos);
   }
   return item;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same BinaryHeap operations, wave-parallel.  `nearest` never holds more than ef + 1 <= 64 items, so it can
+// live in registers, lane i = heap slot i; a push or pop is then a handful of cross-lane moves instead of a chain of
+// dependent LDS round trips driven by lane 0.  Each function performs exactly the element moves of the serial
+// routine it replaces (the path of a sift is a sorted chain, so "shift every smaller ancestor down one level" can
+// be decided for all ancestors at once), hence the same heap layout and the same tie behaviour.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rlane_f(float v, uint32_t l) {
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l));
+}
+
+// place (en, ed) at the hole `pos` and sift it up (h_sift_up with start 0)
+__device__ __forceinline__ void rh_sift_up(uint32_t& hn, float& hd, uint32_t pos, uint32_t en, float ed, int lane) {
+  const uint32_t x = pos + 1, y = (uint32_t)lane + 1;
+  const int bx = 31 - __builtin_clz(x), by = 31 - __builtin_clz(y);
+  const bool onpath = by <= bx && (x >> (bx - by)) == y;  // lane is `pos` or one of its ancestors
+  const bool self = (uint32_t)lane == pos;
+  const bool moves = onpath && !self && !(ed >= hd);  // !h_le(elt, ancestor): the ancestor drops one level
+  const int par = lane > 0 ? (lane - 1) >> 1 : 0;
+  const int pm = __shfl(moves ? 1 : 0, par);  // every lane takes part: a shuffle only sees active source lanes
+  const bool pmoves = lane > 0 && pm != 0;
+  const uint32_t upn = __shfl(hn, par);
+  const float upd = __shfl(hd, par);
+  if (onpath) {
+    if (pmoves) {
+      hn = upn;
+      hd = upd;
+    } else if (self || moves) {
+      hn = en;
+      hd = ed;
+    }
+  }
+}
+
+__device__ __forceinline__ void rh_push(uint32_t& hn, float& hd, uint32_t& n, uint32_t en, float ed, int lane) {
+  rh_sift_up(hn, hd, n, en, ed, lane);
+  n += 1;
+}
+
+// BinaryHeap::pop: the last item replaces the root, sift_down_to_bottom(0), then sift_up; returns the old root
+__device__ __forceinline__ void rh_pop(uint32_t& hn, float& hd, uint32_t& n, int lane) {
+  n -= 1;
+  const uint32_t itn = __builtin_amdgcn_readlane(hn, n);
+  const float itd = rlane_f(hd, n);
+  if (n == 0) return;
+  const uint32_t end = n;
+  // larger child of every node (children are compared before anything moves, as in the serial loop)
+  const uint32_t l = 2u * lane + 1, r = l + 1;
+  const float dl = __shfl(hd, (int)min(l, 63u)), dr = __shfl(hd, (int)min(r, 63u));
+  int big = -1;
+  if (r < end) big = dl >= dr ? (int)r : (int)l;  // h_le(h[l], h[r]) picks the right child
+  else if (l < end) big = (int)l;                  // a lone left child at the very end
+  // the path from the root through the larger children
+  bool onp = lane == 0;
+  const int par = lane > 0 ? (lane - 1) >> 1 : 0;
+  const int pbig = __shfl(big, par);
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const bool ponp = __shfl(onp ? 1 : 0, par) != 0;
+    onp = onp || (lane > 0 && ponp && pbig == lane);
+  }
+  const int src = big >= 0 ? big : lane;
+  const uint32_t cn = __shfl(hn, src);
+  const float cd = __shfl(hd, src);
+  const bool bottom_here = onp && big < 0;
+  if (onp && big >= 0) {
+    hn = cn;
+    hd = cd;
+  }
+  const uint32_t bottom = (uint32_t)__builtin_ctzll(__ballot(bottom_here));
+  rh_sift_up(hn, hd, bottom, itn, itd, lane);
+}
+
+// Heaps too large for registers (`candidates`) stay in LDS, but all lanes help.  Sift-up: the ancestors of the
+// slot are read together, the smaller ones drop one level, the item lands above them.
+__device__ __forceinline__ void lds_sift_up_parallel(HItem* h, uint32_t pos, const HItem c, int lane) {
+  const uint32_t x = pos + 1;  // 1-based index of the slot
+  const int depth = 31 - __builtin_clz(x);
+  const bool valid = lane >= 1 && lane <= depth;  // lane j holds ancestor j (1 = parent)
+  HItem a = c;
+  if (valid) a = h[(x >> lane) - 1];
+  const bool moves = valid && !h_le(c, a);
+  const uint64_t mb = __ballot(moves) >> 1;                        // bit j-1: ancestor j moves
+  const uint32_t m = (uint32_t)__builtin_ctzll(~mb);               // they form a run from the parent up
+  if (valid && (uint32_t)lane <= m) h[(x >> (lane - 1)) - 1] = a;  // ancestor j -> slot of ancestor j-1
+  if (lane == 0) h[(x >> m) - 1] = c;
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void lds_push_parallel(HItem* h, uint32_t& n, const HItem c, int lane) {
+  lds_sift_up_parallel(h, n, c, lane);
+  n += 1;
+}
+
+// BinaryHeap::pop on an LDS heap: sift_down_to_bottom walks two levels per LDS round trip (children and
+// grandchildren of the hole are fetched together), then the parallel sift-up.  Returns the old root in every lane.
+__device__ __forceinline__ HItem lds_pop_parallel(HItem* h, uint32_t& n, int lane) {
+  n -= 1;
+  const HItem item = h[n];
+  if (n == 0) return item;
+  const HItem root = h[0];
+  const uint32_t end = n;
+  uint32_t pos = 0;
+  for (;;) {
+    const uint32_t c1 = 2 * pos + 1;
+    if (c1 >= end) break;  // the hole is a leaf
+    const uint32_t idx = lane < 2 ? c1 + lane : 4 * pos + 3 + (lane - 2);  // lanes 2,3 / 4,5: children of c1 / c1+1
+    HItem v = item;
+    if (lane < 6 && idx < end) v = h[idx];
+    const bool two1 = c1 + 1 < end;
+    const uint32_t l1 = two1 && rlane_f(v.d, 0) >= rlane_f(v.d, 1) ? 1u : 0u;  // h_le(left, right): right child
+    const uint32_t b1 = c1 + l1;
+    const HItem cv = HItem{(uint32_t)__builtin_amdgcn_readlane(v.node, l1), rlane_f(v.d, l1)};
+    if (!two1) {  // a lone left child at the very end: it moves up and the walk ends
+      if (lane == 0) h[pos] = cv;
+      pos = b1;
+      break;
+    }
+    const uint32_t g1 = 2 * b1 + 1, la = 2 + 2 * l1;
+    if (g1 >= end) {
+      if (lane == 0) h[pos] = cv;
+      pos = b1;
+      break;
+    }
+    const bool two2 = g1 + 1 < end;
+    const uint32_t l2 = two2 && rlane_f(v.d, la) >= rlane_f(v.d, la + 1) ? la + 1 : la;
+    const HItem gv = HItem{(uint32_t)__builtin_amdgcn_readlane(v.node, l2), rlane_f(v.d, l2)};
+    if (lane == 0) {
+      h[pos] = cv;
+      h[b1] = gv;
+    }
+    pos = g1 + (l2 - la);
+    if (!two2) break;
+  }
+  __builtin_amdgcn_wave_barrier();
+  lds_sift_up_parallel(h, pos, item, lane);
+  return root;
 }
 
 // Distances of the wave's query to the `np` (<= 64) rows listed in pending[], into pdist[]: one lane per row,
@@ -189,6 +328,8 @@ __host__ __device__ inline size_t graph_lds_bytes(uint32_t dpad, uint32_t ef, ui
   return (b + 15) & ~(size_t)15;
 }
 
+// RH: `nearest` in registers + wave-parallel heap pushes (ef <= 63); otherwise both heaps in LDS, driven by lane 0.
+template <bool RH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void hnsw_search_kernel(const GraphView g, const float* __restrict__ queries,
                                                          uint32_t B, uint32_t k, uint32_t ef_final, uint32_t cand_cap,
                                                          uint32_t* __restrict__ visited /* [B][words] zero on entry */,
@@ -234,11 +375,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #endif
   for (uint32_t layer = g.top_level + 1; layer-- > 0;) {
     const uint32_t ef = layer == 0 ? ef_final : 1;
-    uint32_t nC = 0, nN = 0, nT = 0;  // lane 0's copies are authoritative
+    uint32_t nC = 0, nN = 0, nT = 0;  // RH: wave-uniform; else lane 0's copies are authoritative
+    uint32_t nr_node = 0;             // RH: `nearest`, lane i = heap slot i
+    float nr_d = 0.0f;
     bool overflow = false;
     // ---- search_layer(query, res[0].node, ef, layer) ----
     const HItem ep = res[0];
-    if (lane == 0) {
+    if (RH) {
+      lds_push_parallel(cand, nC, ep, lane);
+      rh_push(nr_node, nr_d, nN, ep.node, -ep.d, lane);
+      if (lane == 0) {
+        atomicOr(&vis[ep.node >> 5], 1u << (ep.node & 31));
+        tch[0] = ep.node;
+      }
+    } else if (lane == 0) {
       h_push(cand, nC, ep);
       h_push(near, nN, HItem{ep.node, -ep.d});
       atomicOr(&vis[ep.node >> 5], 1u << (ep.node & 31));
@@ -247,7 +397,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     nT = 1;
     for (;;) {
       STAMP(t0s);
-      if (lane == 0) {
+      if (RH) {
+        uint32_t stop_r = 1, node_r = 0;
+        if (nC > 0) {
+          const HItem cur = lds_pop_parallel(cand, nC, lane);
+          stop_r = cur.d > -rlane_f(nr_d, 0) ? 1u : 0u;  // :499-501
+          node_r = cur.node;
+        }
+        if (lane == 0) {
+          sc[0] = stop_r;
+          sc[1] = node_r;
+        }
+      } else if (lane == 0) {
         uint32_t stop = 0, node = 0;
         if (nC == 0) {
           stop = 1;
@@ -283,7 +444,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         if ((uint32_t)lane < cnt) {
           const uint32_t bit = 1u << (nb & 31);
           fresh = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;  // visited.insert (:506-507)
-          keep = fresh && g.deleted[nb] == 0;                  // :511-513
+          keep = fresh && (g.any_deleted == 0 || g.deleted[nb] == 0);  // :511-513
         }
         const uint64_t fm = __ballot(fresh), km = __ballot(keep);
         const uint64_t lt = (1ull << lane) - 1;
@@ -314,25 +475,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         // shrinks while the neighbours are applied, so a candidate that fails against the worst as it
         // stands now can never be admitted later in this hop: all lanes test that at once and lane 0
         // walks only the survivors (in order, re-testing against the current worst).
-        const uint32_t nN0 = __builtin_amdgcn_readfirstlane(nN);
-        const float worst0 = -near[0].d;
-        const bool maybe = (uint32_t)lane < np && (nN0 < ef || pdist[lane] < worst0);
-        uint64_t todo = __ballot(maybe);
-        if (lane == 0) {
-          float worst = worst0;
+        if (RH) {
+          const float pd = (uint32_t)lane < np ? pdist[lane] : 0.0f;
+          const uint32_t pn = (uint32_t)lane < np ? pending[lane] : 0u;
+          float worst = -rlane_f(nr_d, 0);
+          uint64_t todo = __ballot((uint32_t)lane < np && (nN < ef || pd < worst));
           while (todo) {
             const uint32_t i = (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1;
-            const float d = pdist[i];
+            const float d = rlane_f(pd, i);
             if (d < worst || nN < ef) {
               if (nC >= cand_cap) {
-                sc[2] = 1;
+                overflow = true;
                 break;
               }
-              h_push(cand, nC, HItem{pending[i], d});
-              h_push(near, nN, HItem{pending[i], -d});
-              if (nN > ef) (void)h_pop(near, nN);
-              worst = -near[0].d;
+              const uint32_t node_i = __builtin_amdgcn_readlane(pn, i);
+              lds_push_parallel(cand, nC, HItem{node_i, d}, lane);
+              rh_push(nr_node, nr_d, nN, node_i, -d, lane);
+              if (nN > ef) rh_pop(nr_node, nr_d, nN, lane);
+              worst = -rlane_f(nr_d, 0);
+            }
+          }
+          if (overflow && lane == 0) sc[2] = 1;
+        } else {
+          const uint32_t nN0 = __builtin_amdgcn_readfirstlane(nN);
+          const float worst0 = -near[0].d;
+          const bool maybe = (uint32_t)lane < np && (nN0 < ef || pdist[lane] < worst0);
+          uint64_t todo = __ballot(maybe);
+          if (lane == 0) {
+            float worst = worst0;
+            while (todo) {
+              const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+              todo &= todo - 1;
+              const float d = pdist[i];
+              if (d < worst || nN < ef) {
+                if (nC >= cand_cap) {
+                  sc[2] = 1;
+                  break;
+                }
+                h_push(cand, nC, HItem{pending[i], d});
+                h_push(near, nN, HItem{pending[i], -d});
+                if (nN > ef) (void)h_pop(near, nN);
+                worst = -near[0].d;
+              }
             }
           }
         }
@@ -350,7 +535,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #endif
     }
     // ---- result of the layer: nearest in heap order, stable-sorted by distance (:541-553) ----
-    if (lane == 0) sc[3] = nN;
+    if (RH) {
+      if ((uint32_t)lane < nN) near[lane] = HItem{nr_node, nr_d};
+      if (lane == 0) sc[3] = nN;
+    } else if (lane == 0) {
+      sc[3] = nN;
+    }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     const uint32_t nn = sc[3];

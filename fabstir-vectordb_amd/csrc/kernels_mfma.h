@@ -156,8 +156,8 @@ struct MfmaScanArgs {
 // conversion to two MFMA A operands, done late (so the loads of step c+1 fly during the MFMAs of step c)
 template <int ST>
 struct RowChunk16 {
-  float4 v[ST == 0 ? 4 : 1];
-  h8v h[ST == 0 ? 1 : 2];
+  float4 v[4];  // ST == 0
+  h8v h[2];     // ST == 1
 };
 template <int ST>
 __device__ __forceinline__ void load_a16(const void* __restrict__ pool_data, uint32_t blk, uint32_t d4, uint32_t c4,
