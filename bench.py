@@ -103,6 +103,8 @@ def main():
                     help="device: the layered walk runs on the GPU (one launch per batch); host: on the host with one "
                          "candidate-scoring launch per hop (the north_star's split).  Identical results.")
     ap.add_argument("--compare-host-walk", type=int, default=5, help="extra steps timed with the host walk (0 = skip)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight during the timed region (1 = each step collected before the next is enqueued)")
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--spread", type=float, default=1.5)
     args = ap.parse_args()
@@ -214,18 +216,40 @@ def main():
         run(i, nprobe, ef)
     log("warmup done")
     ctx_ivf.set_profiling(2)
+    ctx_hnsw.set_profiling(2)     # HIP events around the traversal kernel (its own stream)
     hyb.ivf_device_stage_times()  # reset accumulators
     hnsw = hyb.hnsw()
+    hnsw.graph_kernel_times()
     evals0, hops0 = hnsw.dist_evals(), hnsw.hops()
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
     ctx_ivf.synchronize()
     ctx_hnsw.synchronize()
+    depth = max(1, min(args.in_flight, 4)) if sharded is None else 1
     t0 = time.perf_counter()
     last = None
-    for i in range(args.steps):
-        last = run(i, nprobe, ef)
+    if depth == 1:
+        for i in range(args.steps):
+            last = run(i, nprobe, ef)
+    else:
+        # `depth` batches in flight: step i is enqueued (graph walk on its own stream, IVF chain behind the previous
+        # batch's on the IVF stream) before step i - depth is collected and merged on the host.  Every step's
+        # results are complete, on the host, inside the timed region.
+        t_begin = t_end = 0.0
+        for i in range(args.steps):
+            if i >= depth:
+                ta = time.perf_counter()
+                last = hyb.search_dev_end((i - depth) % depth)
+                t_end += time.perf_counter() - ta
+            ta = time.perf_counter()
+            hyb.search_dev_begin(i % depth, qdev[i % nb], B, k, now=now, hnsw_ef=ef, ivf_n_probe=nprobe, dim=d)
+            t_begin += time.perf_counter() - ta
+        for i in range(max(args.steps - depth, 0), args.steps):
+            ta = time.perf_counter()
+            last = hyb.search_dev_end(i % depth)
+            t_end += time.perf_counter() - ta
+        log(f"host time per step: enqueue {t_begin / args.steps * 1e3:.3f} ms, collect+merge (incl. waiting) {t_end / args.steps * 1e3:.3f} ms")
     ctx_ivf.synchronize()
     ctx_hnsw.synchronize()
     if dist is not None:
@@ -237,7 +261,15 @@ def main():
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    graph_ms_sum, graph_launches, graph_rows, graph_hops = hnsw.graph_kernel_times()
+    # per-stage timing of the IVF chain: a few more steps, one batch at a time (the events of one chain would be
+    # overwritten by the next while several batches are in flight)
+    hyb.ivf_device_stage_times()
+    for i in range(5):
+        run(i, nprobe, ef)
     ctx_ivf.set_profiling(0)
+    ctx_hnsw.set_profiling(0)
+    hnsw.graph_kernel_times()
     n_prof, stage = hyb.ivf_device_stage_times()
     stats = hyb.ivf_device_last_stats()
     evals, hops = hnsw.dist_evals() - evals0, hnsw.hops() - hops0
@@ -267,23 +299,42 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     log(f"{args.steps} steps: {ms_per_step:.3f} ms/step, {qps:.0f} QPS, recall@{k}={recall:.4f}")
 
-    # ---- roofline of the dominant kernel (list scan) ----
-    scan_ms = stage["fine_scan"] / max(n_prof, 1)
+    # ---- roofline of the list scan (the HBM-bound kernel of the path) ----
+    # ALGORITHMIC bytes per launch = sum over queries of (rows in its probed lists) x d x 4 (section 8d's
+    # nprobe*(N/nlist)*d*s per query, measured rather than averaged).  The kernel that does this work is the
+    # matrix-core filter (scan_mfma_kernel) when the matrix-core path runs, else scan_topk_kernel; its duration is
+    # measured live with HIP events on its launch stream.
+    mfma_path = stage.get("mfma_filter_kernel", 0.0) > 0.0
+    scan_ms = (stage["mfma_filter_kernel"] if mfma_path else stage["fine_scan"]) / max(n_prof, 1)
     alg_bytes = stats["rows_scanned"] * d * 4  # rows each query's probed lists hold x row bytes
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    phys_bytes = stats["list_rows_touched"] * d * (2 if mfma_path else 4)  # every probed list read once (fp16 mirror)
+    graph_ms = graph_ms_sum / max(graph_launches, 1)
+    if args.hnsw_traversal == "device":
+        evals, hops = graph_rows, graph_hops
+    gather_bytes = (evals / max(args.steps, 1)) * d * 4  # rows scored per step x row bytes
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
         "frac": round(achieved / 8000.0, 4), "traffic": None,
-        "kernel": "fvdb::scan_topk_kernel<16, 1, 1> (IVF list scan)", "kernel_ms": round(scan_ms, 4),
+        "kernel": ("fvdb::scan_mfma_kernel<2, 1, 0> (IVF list scan: fp16 MFMA filter over every probed row)" if mfma_path
+                   else "fvdb::scan_topk_kernel<16, 1, 1> (IVF list scan, exact)"),
+        "kernel_ms": round(scan_ms, 4),
         "algorithmic_bytes_per_launch": int(alg_bytes),
         "rows_scanned_per_query": round(stats["rows_scanned"] / B, 1),
-        "physical_lower_bound_bytes_per_launch": int(stats["list_rows_touched"] * d * 4),
+        "physical_lower_bound_bytes_per_launch": int(phys_bytes),
+        "physical_lower_bound_GBps": round(phys_bytes / (scan_ms * 1e-3) / 1e9, 1) if scan_ms > 0 else 0.0,
+        "physical_lower_bound_frac_of_hbm_peak": round(phys_bytes / (scan_ms * 1e-3) / 1e9 / 8000.0, 4) if scan_ms > 0 else 0.0,
         "pair_dims_per_s": round(stats["rows_scanned"] * d / (scan_ms * 1e-3), 1) if scan_ms > 0 else 0.0,
-        "valu_lane_ops_frac_of_measured_peak": round(3 * stats["rows_scanned"] * d / (scan_ms * 1e-3) / 65.9e12, 4)
-        if scan_ms > 0 else 0.0,
-        "note": "queries probing the same list share one read of it, so algorithmic bytes/s can exceed the HBM "
-                "peak; the kernel is bound by f32 VALU issue (3 exact ops per pair-dim), see DESIGN.md",
+        "note": "queries probing the same list share one read of it (32 per pass), so algorithmic bytes/s exceed the "
+                "HBM peak; the physical lower bound is every probed list streamed once per launch, see DESIGN.md",
         "stage_ms": {k_: round(v / max(n_prof, 1), 4) for k_, v in stage.items()},
+        "graph_traversal_kernel": {
+            "kernel": "fvdb::hnsw_search_kernel<true> (one wavefront per query, whole traversal on the GPU)",
+            "kernel_ms": round(graph_ms, 4), "launches_timed": graph_launches,
+            "rows_scored_per_query": round(evals / max(args.steps, 1) / B, 1),
+            "gathered_GBps": round(gather_bytes / (graph_ms * 1e-3) / 1e9, 1) if graph_ms > 0 else 0.0,
+            "note": "latency-bound pointer chase (pop -> adjacency -> visited -> rows -> heaps per hop); it runs "
+                    "concurrently with the IVF chain on its own stream and is the longer of the two"},
         "hnsw": {"hops_per_step": round(hops / args.steps, 1), "dist_evals_per_query": round(evals / args.steps / B, 1)},
     }
 
@@ -291,10 +342,17 @@ def main():
     # rocprofv3 passes by tools/pmc_traffic.sh for this same command and committed under profiles/;
     # gfx950: FETCH_SIZE counts wide streaming reads at half their bytes => doubled, see MI355X_MICROARCH.md)
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["list_scan"]
-        if N == 1_000_000 and nprobe == 48 and world == 1:
+        pmj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        pm = pmj["list_scan"]
+        if N == 1_000_000 and nprobe == pmj.get("nprobe") and world == 1 and mfma_path:
             roofline["traffic"] = int((2 * pm["FETCH_SIZE_KB_avg"] + pm["WRITE_SIZE_KB_avg"]) * 1024)
             roofline["traffic_note"] = "bytes per launch beyond L2 (Infinity Cache + HBM), 2*FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json"
+            roofline["pmc"] = {
+                "source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes of this command)",
+                "mfma_busy_frac_of_busy_simd_cycles": {
+                    name: round(pmj[name]["SQ_VALU_MFMA_BUSY_CYCLES_avg"] / (4.0 * pmj[name]["SQ_BUSY_CU_CYCLES_avg"]), 4)
+                    for name in ("coarse_gemm", "threshold_pass", "list_scan") if name in pmj},
+            }
     except Exception:
         pass
 
@@ -312,7 +370,7 @@ def main():
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "c3: 1M x 384 f32 hybrid HNSW/IVF (10K-vector chunks), batch 1024, k 10",
                        "n_vectors": N, "dim": d, "batch": B, "k": k, "recent_frac_hnsw": args.recent_frac,
-                       "nlist": args.nlist, "nprobe": nprobe, "hnsw_ef": ef, "hnsw_M": 16, "hnsw_M0": 32, "hnsw_traversal": args.hnsw_traversal,
+                       "nlist": args.nlist, "nprobe": nprobe, "hnsw_ef": ef, "hnsw_M": 16, "hnsw_M0": 32, "hnsw_traversal": args.hnsw_traversal, "batches_in_flight": depth,
                        "other_traversal_mode": other, "hnsw_device_fallbacks": hnsw.device_fallbacks(),
                        "recall_at_10": round(recall, 4), "recall_target": args.recall_target, "sweep": sweep,
                        "generator": f"gaussian mixture: 4096 comps, means {args.spread}*N(0,I) in a rank-{args.latent} latent space, "

@@ -87,7 +87,16 @@ SIGNATURES = {
     "fvdb_graph_upload": (i32, [vp, u32, u32p, C.POINTER(C.c_uint8), u32p, u32p, u32]),
     "fvdb_graph_set_deleted": (i32, [vp, u32, i32]),
     "fvdb_graph_search_dev": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp]),
-    "fvdb_graph_kernel_times": (i32, [vp, f32p, u32p]),
+    "fvdb_graph_search_dev_slot": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp, vp, vp]),
+    "fvdb_ctx_device": (i32, [vp]),
+    "fvdb_host_alloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
+    "fvdb_host_free": (None, [vp, vp]),
+    "fvdb_dev_download_async": (i32, [vp, vp, vp, C.c_size_t]),
+    "fvdb_event_create": (i32, [vp, C.POINTER(vp)]),
+    "fvdb_event_destroy": (None, [vp]),
+    "fvdb_event_record": (i32, [vp, vp]),
+    "fvdb_event_wait": (i32, [vp, vp]),
+    "fvdb_graph_kernel_times": (i32, [vp, f32p, u32p, u64p, u64p]),
     "fvdb_scorer_launch": (i32, [vp, u32, u32]),
     "fvdb_scorer_wait": (i32, [vp]),
 }

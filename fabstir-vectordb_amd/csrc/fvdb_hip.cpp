@@ -225,8 +225,10 @@ struct fvdb_graph {
   uint32_t n = 0, entry = 0, top_level = 0, n_slots = 0;
   DBuf d_level, d_deleted, d_slot_of, d_slot_start, d_adj, d_adj0;
   uint32_t stride0 = 0;
-  DBuf s_q, s_visited, s_touched;
-  uint32_t vis_B = 0, vis_words = 0, vis_tcap = 0;
+  DBuf s_q, d_counters;
+  static constexpr uint32_t kSlots = 4;  // batches that may be in flight at once, each on its own stream
+  DBuf s_visited[kSlots], s_touched[kSlots];
+  uint32_t vis_B[kSlots] = {0, 0, 0, 0}, vis_words = 0, vis_tcap = 0;
   bool uploaded = false;
   // profiling: HIP events around the last launches of the traversal kernel (ring of 64)
   std::vector<uint8_t> h_deleted;  // host copy of the flags: searches skip the per-neighbour flag load when none is set
@@ -548,15 +550,16 @@ int run_fine_mfma(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint
   if (ctx->profiling) (void)hipEventRecord(ivf->sev[3], ctx->stream);
 
   hipLaunchKernelGGL(prep_queries_kernel, dim3(cdiv(B + 1, 4)), dim3(256), 0, ctx->stream, qpad, B, ivf->dpad,
-                     (_Float16*)ivf->s_qh.p, ivf->s_qn2.as<float>());
+                     (_Float16*)ivf->s_qh.p, ivf->s_qn2.as<float>(), ivf->s_cnt.as<uint32_t>(), nlist,
+                     ivf->s_scnt.as<uint32_t>(), ivf->s_mslots.as<uint32_t>());
   hipLaunchKernelGGL(first_probe_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, probes, B, np,
                      ivf->t_len.as<uint32_t>(), 256u, ivf->s_pa.as<uint32_t>());
   auto plan = [&](const uint32_t* pr, uint32_t n, uint32_t npp, uint32_t sb, unsigned long long* stats) {
-    (void)hipMemsetAsync(ivf->s_cnt.p, 0, (size_t)nlist * 4, ctx->stream);
+    // cnt[] is zero on entry: cleared by prep_queries_kernel for the first plan, by plan_scan_kernel for the second
     hipLaunchKernelGGL(plan_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, pr, n, ivf->s_cnt.as<uint32_t>());
     hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ivf->s_cnt.as<uint32_t>(), lists.off,
                        ivf->t_len.as<uint32_t>(), nlist, sb, Q, ivf->s_eoff.as<uint32_t>(), ivf->s_ioff.as<uint32_t>(),
-                       ivf->s_fill.as<uint32_t>(), scal + 2, scal + 3, stats);
+                       ivf->s_fill.as<uint32_t>(), scal + 2, scal + 3, stats, ivf->s_cnt.as<uint32_t>());
     hipLaunchKernelGGL(plan_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, pr, n, npp,
                        ivf->s_eoff.as<uint32_t>(), ivf->s_fill.as<uint32_t>(), ivf->s_entries.as<uint2>());
   };
@@ -587,7 +590,6 @@ int run_fine_mfma(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint
   a.capA = (uint32_t)std::max(1, capA_env);
 
   // A. threshold: MFMA pass over the first segment of a near list -> (k+6)-th smallest v -> thr
-  HIPCHK(ctx, hipMemsetAsync(ivf->s_mslots.p, 0xFF, (size_t)B * 64 * 4, ctx->stream));
   plan(ivf->s_pa.as<uint32_t>(), B, 1, segbA, nullptr);
   a.segb = segbA;
   launch_mfma<1>(ctx, a, M, half_rows, grid);
@@ -596,7 +598,6 @@ int run_fine_mfma(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint
                      x_rounded, ivf->s_thr.as<float>());
 
   // B. filter over all probed lists
-  HIPCHK(ctx, hipMemsetAsync(ivf->s_scnt.p, 0, (size_t)(B + 2) * 4, ctx->stream));
   plan(probes, B * np, np, segb, (unsigned long long*)(scal + 4));
   a.segb = segb;
   if (ctx->profiling) (void)hipEventRecord(ivf->sev[6], ctx->stream);
@@ -766,6 +767,8 @@ int fvdb_ctx_create(int device, fvdb_ctx** out) {
   return FVDB_OK;
 }
 
+int fvdb_ctx_device(fvdb_ctx* ctx) { return ctx ? ctx->device : -1; }
+
 void fvdb_ctx_destroy(fvdb_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
@@ -807,6 +810,50 @@ int fvdb_dev_download(fvdb_ctx* ctx, void* dst, const void* src, size_t bytes) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FVDB_OK;
 }
+// ---- pieces for keeping more than one batch in flight (pinned host memory, non-blocking copies, events) ----
+int fvdb_host_alloc(fvdb_ctx* ctx, size_t bytes, void** out) {
+  *out = nullptr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipHostMalloc(out, std::max<size_t>(bytes, 16), hipHostMallocDefault));
+  return FVDB_OK;
+}
+void fvdb_host_free(fvdb_ctx* ctx, void* p) {
+  (void)ctx;
+  if (p) (void)hipHostFree(p);
+}
+int fvdb_dev_download_async(fvdb_ctx* ctx, void* dst_pinned, const void* src, size_t bytes) {
+  HIPCHK(ctx, hipMemcpyAsync(dst_pinned, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return FVDB_OK;
+}
+struct fvdb_event {
+  hipEvent_t ev = nullptr;
+};
+int fvdb_event_create(fvdb_ctx* ctx, fvdb_event** out) {
+  *out = nullptr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  fvdb_event* e = new (std::nothrow) fvdb_event();
+  if (!e) return FVDB_E_OOM;
+  if (hipEventCreateWithFlags(&e->ev, hipEventDisableTiming) != hipSuccess) {
+    delete e;
+    FAIL(ctx, FVDB_E_HIP, "hipEventCreate failed");
+  }
+  *out = e;
+  return FVDB_OK;
+}
+void fvdb_event_destroy(fvdb_event* e) {
+  if (!e) return;
+  if (e->ev) (void)hipEventDestroy(e->ev);
+  delete e;
+}
+int fvdb_event_record(fvdb_ctx* ctx, fvdb_event* e) {
+  HIPCHK(ctx, hipEventRecord(e->ev, ctx->stream));
+  return FVDB_OK;
+}
+int fvdb_event_wait(fvdb_ctx* ctx, fvdb_event* e) {
+  HIPCHK(ctx, hipEventSynchronize(e->ev));
+  return FVDB_OK;
+}
+
 int fvdb_timer_start(fvdb_ctx* ctx) {
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   return FVDB_OK;
@@ -1748,7 +1795,8 @@ void fvdb_graph_destroy(fvdb_graph* g) {
   if (!g) return;
   (void)hipSetDevice(g->store->ctx->device);
   (void)hipStreamSynchronize(g->store->ctx->stream);
-  DBuf* bufs[] = {&g->d_level, &g->d_deleted, &g->d_slot_of, &g->d_slot_start, &g->d_adj, &g->d_adj0, &g->s_q, &g->s_visited, &g->s_touched};
+  DBuf* bufs[] = {&g->d_level, &g->d_deleted, &g->d_slot_of, &g->d_slot_start, &g->d_adj, &g->d_adj0, &g->s_q, &g->d_counters, &g->s_visited[0], &g->s_visited[1], &g->s_visited[2], &g->s_visited[3],
+                  &g->s_touched[0], &g->s_touched[1], &g->s_touched[2], &g->s_touched[3]};
   for (DBuf* b : bufs) b->release();
   delete g;
 }
@@ -1804,7 +1852,7 @@ int fvdb_graph_upload(fvdb_graph* g, uint32_t n, const uint32_t* levels, const u
   g->top_level = levels[entry_node];
   g->n_slots = slots;
   g->uploaded = true;
-  g->vis_B = 0;  // node count may have changed: re-size (and re-zero) the visited bitmaps
+  for (auto& v : g->vis_B) v = 0;  // node count may have changed: re-size (and re-zero) the visited bitmaps
   return FVDB_OK;
 }
 
@@ -1824,8 +1872,18 @@ int fvdb_graph_set_deleted(fvdb_graph* g, uint32_t node, int deleted) {
 int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_t k, uint32_t ef,
                           uint32_t* out_nodes_dev, float* out_dist_dev, uint32_t* out_counts_dev,
                           uint32_t* out_status_dev) {
+  return fvdb_graph_search_dev_slot(g, nullptr, 0, q_dev, B, k, ef, out_nodes_dev, out_dist_dev, out_counts_dev,
+                                    out_status_dev);
+}
+
+int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t k,
+                               uint32_t ef, uint32_t* out_nodes_dev, float* out_dist_dev, uint32_t* out_counts_dev,
+                               uint32_t* out_status_dev) {
   fvdb_store* s = g->store;
-  fvdb_ctx* ctx = s->ctx;
+  fvdb_ctx* ctx = on ? on : s->ctx;
+  if (slot >= fvdb_graph::kSlots) FAIL(ctx, FVDB_E_INVALID, "slot out of range");
+  if (on && on->device != s->ctx->device) FAIL(ctx, FVDB_E_INVALID, "context of another device");
+  if (s->d != s->dpad && slot != 0) FAIL(ctx, FVDB_E_UNSUPPORTED, "padded dimensions use slot 0 only");
   if (!g->uploaded) FAIL(ctx, FVDB_E_INVALID, "graph not uploaded");
   if (k == 0 || ef == 0 || ef > 4096) FAIL(ctx, FVDB_E_UNSUPPORTED, "ef must be in 1..4096");
   if (B == 0) return FVDB_OK;
@@ -1840,13 +1898,16 @@ int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_
   // visited-log capacity per query (FVDB_GRAPH_TCAP: test hook that forces the overflow -> host-walk fallback)
   const uint32_t words = (g->n + 31) / 32;
   const uint32_t tcap = getenv("FVDB_GRAPH_TCAP") ? std::max(1, atoi(getenv("FVDB_GRAPH_TCAP"))) : 8192;
-  if (B > g->vis_B || words != g->vis_words || tcap != g->vis_tcap) {  // bitmaps are left all-zero by every search: zero once
-    HIPCHK(ctx, g->s_visited.ensure((size_t)B * words * 4));
-    HIPCHK(ctx, hipMemsetAsync(g->s_visited.p, 0, g->s_visited.cap, ctx->stream));
-    HIPCHK(ctx, g->s_touched.ensure((size_t)B * tcap * 4));
-    g->vis_B = B;
+  if (words != g->vis_words || tcap != g->vis_tcap) {
+    for (auto& v : g->vis_B) v = 0;
     g->vis_words = words;
     g->vis_tcap = tcap;
+  }
+  if (B > g->vis_B[slot]) {  // bitmaps are left all-zero by every search: zero once
+    HIPCHK(ctx, g->s_visited[slot].ensure((size_t)B * words * 4));
+    HIPCHK(ctx, hipMemsetAsync(g->s_visited[slot].p, 0, g->s_visited[slot].cap, ctx->stream));
+    HIPCHK(ctx, g->s_touched[slot].ensure((size_t)B * tcap * 4));
+    g->vis_B[slot] = B;
   }
   const uint32_t cand_cap = std::max<uint32_t>(1024, 8 * ef);
   const size_t lds = graph_lds_bytes(s->dpad, ef, cand_cap);
@@ -1859,7 +1920,12 @@ int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_
   }
   GraphView gv{s->data, g->d_level.as<uint32_t>(), g->d_deleted.as<uint32_t>(), g->d_slot_of.as<uint32_t>(),
                g->d_slot_start.as<uint32_t>(), g->d_adj.as<uint32_t>(), g->d_adj0.as<uint32_t>(), g->stride0, g->n,
-               s->dpad, g->entry, g->top_level, g->n_deleted ? 1u : 0u, nullptr};
+               s->dpad, g->entry, g->top_level, g->n_deleted ? 1u : 0u, nullptr, nullptr};
+  if (!g->d_counters.p) {
+    HIPCHK(ctx, g->d_counters.ensure(16));
+    HIPCHK(ctx, hipMemsetAsync(g->d_counters.p, 0, 16, ctx->stream));
+  }
+  gv.counters = (unsigned long long*)g->d_counters.p;
 #ifdef FVDB_GRAPH_STAMPS
   static unsigned long long* d_stamps = nullptr;
   if (!d_stamps) {
@@ -1875,7 +1941,7 @@ int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_
   }
 #endif
   hipEvent_t* ev = nullptr;
-  if (ctx->profiling) {
+  if (s->ctx->profiling) {  // the store's context carries the switch, whichever stream the launch goes to
     ev = g->kev[g->kev_n & 63];
     if (!ev[0]) {
       (void)hipEventCreate(&ev[0]);
@@ -1885,11 +1951,11 @@ int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_
   }
   if (rh)
     hipLaunchKernelGGL(hnsw_search_kernel<true>, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
-                       g->s_visited.as<uint32_t>(), words, g->s_touched.as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
+                       g->s_visited[slot].as<uint32_t>(), words, g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
                        out_counts_dev, out_status_dev);
   else
     hipLaunchKernelGGL(hnsw_search_kernel<false>, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
-                       g->s_visited.as<uint32_t>(), words, g->s_touched.as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
+                       g->s_visited[slot].as<uint32_t>(), words, g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
                        out_counts_dev, out_status_dev);
   if (ev) {
     (void)hipEventRecord(ev[1], ctx->stream);
@@ -1899,12 +1965,19 @@ int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_
   return FVDB_OK;
 }
 
-int fvdb_graph_kernel_times(fvdb_graph* g, float* ms_sum, uint32_t* launches) {
+int fvdb_graph_kernel_times(fvdb_graph* g, float* ms_sum, uint32_t* launches, uint64_t* rows_scored, uint64_t* hops) {
   fvdb_ctx* ctx = g->store->ctx;
   *ms_sum = 0.0f;
   *launches = 0;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  unsigned long long c[2] = {0, 0};
+  if (g->d_counters.p) {
+    HIPCHK(ctx, hipMemcpy(c, g->d_counters.p, 16, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemset(g->d_counters.p, 0, 16));
+  }
+  if (rows_scored) *rows_scored = c[0];
+  if (hops) *hops = c[1];
   const uint32_t n = std::min<uint32_t>(g->kev_n, 64);
   for (uint32_t i = 0; i < n; ++i) {
     hipEvent_t* ev = g->kev[(g->kev_n - 1 - i) & 63];

@@ -29,6 +29,7 @@ struct GraphView {
   uint32_t stride0;           //   (one dependent load instead of three on the layer that takes ~all hops)
   uint32_t n, dpad, entry, top_level;
   uint32_t any_deleted;       // 0: no node is flagged, the per-neighbour flag load is skipped
+  unsigned long long* counters;  // [0] rows scored, [1] hops — summed over queries (roofline accounting)
   unsigned long long* stamps;  // diagnostic builds only (FVDB_GRAPH_STAMPS): per-phase cycle sums
 };
 
@@ -236,7 +237,7 @@ __device__ __forceinline__ HItem lds_pop_parallel(HItem* h, uint32_t& n, int lan
 // order, so the rows are first pulled towards the core all at once: every 128-byte line of every row is touched
 // by one `global_load_lds_dword` (data discarded into an LDS scratch word per lane, no VGPR held), np*12 loads in
 // flight together.  Each lane then streams its own row (row-major, 16 bytes per load, 32 dims per batch, two
-// batches in flight) out of L2; the query sits in LDS and is read with broadcast loads one batch ahead.
+// batch ahead) out of L2; the query sits in LDS and is read with broadcast loads.
 __device__ __forceinline__ void score_pending(const GraphView& g, const float* q_lds, float* pf_scratch,
                                               const uint32_t* pending, float* pdist, uint32_t np, int lane) {
   const uint32_t dpad = g.dpad;
@@ -274,29 +275,27 @@ __device__ __forceinline__ void score_pending(const GraphView& g, const float* q
       }
     };
     uint32_t done = 0;
-    if (nb >= 6) {
-      // rows two batches ahead, query one batch ahead; six batches per trip so every buffer index is static
-      float4 r0[8], r1[8], r2[8], qa[8], qb[8];
-      const uint32_t nb6 = nb - nb % 6;
+    if (nb >= 2) {
+      // rows one batch ahead (64 VGPRs of row data in flight), the query batch read from LDS as the fold starts;
+      // two batches per trip so both buffer indices are static.  Kept this lean on purpose: at <= 152 VGPRs two
+      // traversal waves AND a list-scan wave fit one SIMD, so the IVF chain of the same step (and the traversal of
+      // the next batch in flight) run beside this kernel instead of queueing behind it.
+      float4 r0[8], r1[8], qa[8];
+      const uint32_t nb2 = nb - nb % 2;
       issue(0, r0);
-      issue(1, r1);
-      issue_q(0, qa);
-      for (uint32_t bi = 0; bi < nb6; bi += 6) {
-#define FVDB_STEP(K, RC, RN, QC, QN)              \
-  issue(bi + (K) + 2, RN);                        \
-  issue_q(bi + (K) + 1, QN);                      \
-  __builtin_amdgcn_sched_barrier(0);              \
-  fold(RC, QC);                                   \
-  __builtin_amdgcn_sched_barrier(0)
-        FVDB_STEP(0, r0, r2, qa, qb);
-        FVDB_STEP(1, r1, r0, qb, qa);
-        FVDB_STEP(2, r2, r1, qa, qb);
-        FVDB_STEP(3, r0, r2, qb, qa);
-        FVDB_STEP(4, r1, r0, qa, qb);
-        FVDB_STEP(5, r2, r1, qb, qa);
-#undef FVDB_STEP
+      for (uint32_t bi = 0; bi < nb2; bi += 2) {
+        issue(bi + 1, r1);
+        issue_q(bi, qa);
+        __builtin_amdgcn_sched_barrier(0);
+        fold(r0, qa);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(bi + 2, r0);
+        issue_q(bi + 1, qa);
+        __builtin_amdgcn_sched_barrier(0);
+        fold(r1, qa);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      done = nb6;
+      done = nb2;
     }
     for (uint32_t bi = done; bi < nb; ++bi) {
       float4 t8[8], q8[8];
@@ -330,7 +329,7 @@ __host__ __device__ inline size_t graph_lds_bytes(uint32_t dpad, uint32_t ef, ui
 
 // RH: `nearest` in registers + wave-parallel heap pushes (ef <= 63); otherwise both heaps in LDS, driven by lane 0.
 template <bool RH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void hnsw_search_kernel(const GraphView g, const float* __restrict__ queries,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 3))) void hnsw_search_kernel(const GraphView g, const float* __restrict__ queries,
                                                          uint32_t B, uint32_t k, uint32_t ef_final, uint32_t cand_cap,
                                                          uint32_t* __restrict__ visited /* [B][words] zero on entry */,
                                                          uint32_t words, uint32_t* __restrict__ touched /* [B][tcap] */,
@@ -373,6 +372,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
+  uint32_t rows_scored = 1, hops_done = 0;  // the entry point was scored above
   for (uint32_t layer = g.top_level + 1; layer-- > 0;) {
     const uint32_t ef = layer == 0 ? ef_final : 1;
     uint32_t nC = 0, nN = 0, nT = 0;  // RH: wave-uniform; else lane 0's copies are authoritative
@@ -463,6 +463,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       __builtin_amdgcn_wave_barrier();
       STAMP(t2s);
       STAMP_ADD(1, t1s, t2s);
+      hops_done += 1;
+      rows_scored += np;
       if (np) {
         score_pending(g, q_lds, pf_scratch, pending, pdist, np, lane);
         STAMP(t3s);
@@ -582,6 +584,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     for (int i = 0; i < 8; ++i) atomicAdd(g.stamps + i, t_acc[i]);
   }
 #endif
+  if (lane == 0 && g.counters) {
+    atomicAdd(g.counters + 0, (unsigned long long)rows_scored);
+    atomicAdd(g.counters + 1, (unsigned long long)hops_done);
+  }
   // ---- filter deleted, take k (:451-466) ----
   if (lane == 0) {
     uint32_t w = 0;

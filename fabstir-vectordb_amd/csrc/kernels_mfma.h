@@ -66,8 +66,18 @@ __global__ void pool_row_norms_kernel(const float* __restrict__ src, uint32_t d,
 // ---------------------------------------------------------------------------------------------
 // per batch: fp16 copy of the queries (round to nearest even) and |q|^2.  One wave per query.
 // ---------------------------------------------------------------------------------------------
+// Also clears the per-batch counters of the stages that follow (one launch instead of four memsets):
+// cnt[nlist] = 0 (plan), scnt[B + 2] = 0 (survivor counts, nfail, rescan queue head), slots[64 B] = 0xFFFFFFFF.
 __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, uint32_t B, uint32_t dpad,
-                                                           _Float16* __restrict__ qh, float* __restrict__ qn) {
+                                                           _Float16* __restrict__ qh, float* __restrict__ qn,
+                                                           uint32_t* __restrict__ cnt, uint32_t nlist,
+                                                           uint32_t* __restrict__ scnt, uint32_t* __restrict__ slots) {
+  {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    for (uint32_t i = gid; i < nlist; i += gsz) cnt[i] = 0;
+    for (uint32_t i = gid; i < B + 2; i += gsz) scnt[i] = 0;
+    for (uint32_t i = gid; i < 64 * B; i += gsz) slots[i] = 0xFFFFFFFFu;
+  }
   const int lane = threadIdx.x & 63;
   const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b > B) return;

@@ -111,8 +111,8 @@ void fvh_hnsw_set_threads(void* p, int t) { ((HNSWIndex*)p)->set_threads(t); }
 void fvh_hnsw_set_device_traversal(void* p, int on) { ((HNSWIndex*)p)->set_device_traversal(on != 0); }
 int fvh_hnsw_device_traversal(void* p) { return ((HNSWIndex*)p)->device_traversal(); }
 uint64_t fvh_hnsw_device_fallbacks(void* p) { return ((HNSWIndex*)p)->device_fallbacks(); }
-int fvh_hnsw_graph_kernel_times(void* p, float* ms_sum, uint32_t* launches) {
-  return ((HNSWIndex*)p)->graph_kernel_times(ms_sum, launches);
+int fvh_hnsw_graph_kernel_times(void* p, float* ms_sum, uint32_t* launches, uint64_t* rows_scored, uint64_t* hops) {
+  return ((HNSWIndex*)p)->graph_kernel_times(ms_sum, launches, rows_scored, hops);
 }
 uint32_t fvh_hnsw_dimension(void* p) { return ((HNSWIndex*)p)->dimension(); }
 
@@ -181,6 +181,22 @@ int fvh_hybrid_search_dev(void* p, const float* q_dev, uint32_t B, uint32_t d, u
   c.recent_k = recent_k;
   c.historical_k = historical_k;
   return ((HybridIndex*)p)->search_dev(q_dev, B, d, c, now, ids, dist, counts);
+}
+int fvh_hybrid_search_dev_begin(void* p, uint32_t slot, const float* q_dev, uint32_t B, uint32_t d, uint64_t k, uint64_t ef,
+                                uint64_t nprobe, int search_recent, int search_historical, uint64_t recent_k,
+                                uint64_t historical_k, double now) {
+  HybridSearchConfig c;
+  c.k = k;
+  c.hnsw_ef = ef;
+  c.ivf_n_probe = nprobe;
+  c.search_recent = search_recent != 0;
+  c.search_historical = search_historical != 0;
+  c.recent_k = recent_k;
+  c.historical_k = historical_k;
+  return ((HybridIndex*)p)->search_dev_begin(slot, q_dev, B, d, c, now);
+}
+int fvh_hybrid_search_dev_end(void* p, uint32_t slot, uint64_t* ids, float* dist, uint32_t* counts) {
+  return ((HybridIndex*)p)->search_dev_end(slot, ids, dist, counts);
 }
 int fvh_hnsw_search_dev(void* p, const float* q_dev, uint32_t B, uint32_t d, uint32_t k, uint32_t ef, uint64_t* ids,
                         float* dist, uint32_t* counts) {

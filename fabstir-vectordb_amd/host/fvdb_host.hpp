@@ -140,9 +140,12 @@ class HNSWIndex {
   // Split form for callers that overlap other GPU work with the graph walk: begin enqueues the
   // device-resident traversal (returns false when this search has to use the host walk instead, in which
   // case nothing was enqueued), end waits for it and delivers the results.
-  bool search_dev_begin(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, int* rc);
+  // Device traversal split in two so that several batches can be in flight: begin enqueues the launch and the
+  // result copies on the slot's own stream (slot < kSlots), end waits for that slot and finishes on the host.
+  static constexpr uint32_t kSlots = 4;
+  bool search_dev_begin(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, int* rc, uint32_t slot = 0);
   int search_dev_end(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
-                     uint32_t* counts);
+                     uint32_t* counts, uint32_t slot = 0);
   int mark_deleted(uint64_t id);                                                   // operations.rs:127
   bool is_deleted(uint64_t id) const;
   uint64_t active_count() const;
@@ -170,10 +173,11 @@ class HNSWIndex {
   bool device_traversal() const { return device_traversal_; }
   uint64_t device_fallbacks() const { return n_fallback_; }
   // profiling on: summed HIP-event duration of the traversal kernel's launches since the last call
-  int graph_kernel_times(float* ms_sum, uint32_t* launches) {
+  int graph_kernel_times(float* ms_sum, uint32_t* launches, uint64_t* rows_scored, uint64_t* hops) {
     *ms_sum = 0.0f;
     *launches = 0;
-    return graph_ ? fvdb_graph_kernel_times(graph_, ms_sum, launches) : 0;
+    *rows_scored = *hops = 0;
+    return graph_ ? fvdb_graph_kernel_times(graph_, ms_sum, launches, rows_scored, hops) : 0;
   }
 
  private:
@@ -220,16 +224,24 @@ class HNSWIndex {
   std::vector<Lane> lanes_;
   int sync_graph();
   bool device_path_ok(uint32_t ef) const;
-  int device_launch(const float* q_dev, uint32_t B, uint32_t k, uint32_t ef);
-  int device_collect(uint32_t B, uint32_t k, uint64_t* ids, float* dist, uint32_t* counts, std::vector<uint32_t>& failed);
+  int device_launch(const float* q_dev, uint32_t B, uint32_t k, uint32_t ef, uint32_t slot);
+  int device_collect(uint32_t B, uint32_t k, uint64_t* ids, float* dist, uint32_t* counts, std::vector<uint32_t>& failed,
+                     uint32_t slot);
   int finish_failed(const float* q, bool q_on_device, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
                     uint32_t* counts, const std::vector<uint32_t>& failed);
   int search_host_walk(const float* q, bool q_on_device, uint32_t B, uint32_t k, uint32_t ef, uint64_t* ids,
                        float* dist, uint32_t* counts);
   fvdb_graph* graph_ = nullptr;
   bool graph_dirty_ = true, device_traversal_ = true;
-  void *d_res_nodes_ = nullptr, *d_res_dist_ = nullptr, *d_res_cnt_ = nullptr, *d_res_status_ = nullptr, *d_q_ = nullptr;
-  uint64_t d_res_cap_ = 0, d_q_cap_ = 0;
+  struct DevSlot {  // per in-flight batch: stream (context), device result buffers, pinned host copies
+    fvdb_ctx* ctx = nullptr;  // slot 0 borrows ctx_, the others own theirs
+    void *d_nodes = nullptr, *d_dist = nullptr, *d_cnt = nullptr, *d_status = nullptr;
+    void *h_nodes = nullptr, *h_dist = nullptr, *h_cnt = nullptr, *h_status = nullptr;
+    uint64_t cap = 0;
+  };
+  DevSlot slots_[kSlots];
+  void* d_q_ = nullptr;
+  uint64_t d_q_cap_ = 0;
   uint64_t n_fallback_ = 0;
 
   fvdb_ctx* ctx_;
@@ -295,6 +307,15 @@ class HybridIndex {
   // the HNSW graph (hop scoring on the second stream); results come back to host memory
   int search_dev(const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg, double now,
                  uint64_t* ids, float* dist, uint32_t* counts);
+  // The same search split in two, so that `kSlots` batches can be in flight at once (the graph walk of one
+  // batch occupies one wavefront per SIMD: a second batch's walk runs beside it almost for free).  begin
+  // enqueues everything for the batch (traversal kernel on the slot's stream, IVF chain and its result copies on
+  // the IVF stream) and returns; end waits for that slot only and merges on the host.  The query buffer must stay
+  // valid and unchanged until end.  Mutations between a begin and its end are not allowed.
+  static constexpr uint32_t kSlots = HNSWIndex::kSlots;
+  int search_dev_begin(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
+                       double now);
+  int search_dev_end(uint32_t slot, uint64_t* ids, float* dist, uint32_t* counts);
   uint64_t migrate_with_threshold(double threshold_s, double now);                                // :600
   int remove(uint64_t id, double now);                                                             // delete :904
   uint64_t recent_count() const { return recent_count_; }
@@ -315,8 +336,16 @@ class HybridIndex {
   int search_impl(const float* q, bool q_on_device, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
                   double now, uint64_t* ids, float* dist, uint32_t* counts);
   fvdb_ctx* ctx_ivf_;
-  void *d_hid_ = nullptr, *d_hd_ = nullptr, *d_hc_ = nullptr;  // device result buffers of the IVF part
-  uint64_t d_cap_ = 0;
+  struct Slot {  // one batch in flight
+    void *d_hid = nullptr, *d_hd = nullptr, *d_hc = nullptr;  // device result buffers of the IVF part
+    void *h_hid = nullptr, *h_hd = nullptr, *h_hc = nullptr;  // pinned host copies
+    uint64_t cap = 0;
+    fvdb_event* ivf_done = nullptr;
+    bool active = false, ivf_in_flight = false, hnsw_in_flight = false, recent = false;
+    const float* q = nullptr;
+    uint32_t B = 0, dim = 0, k = 0, rk = 0, hk = 0, ef = 0;
+  };
+  Slot slots_[kSlots];
   HybridConfig cfg_;
   HNSWIndex* recent_;
   IVFIndex* historical_;

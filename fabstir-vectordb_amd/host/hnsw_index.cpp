@@ -137,9 +137,14 @@ HNSWIndex::HNSWIndex(fvdb_ctx* ctx, const HNSWConfig& cfg) : ctx_(ctx), cfg_(cfg
 
 HNSWIndex::~HNSWIndex() {
   if (graph_) fvdb_graph_destroy(graph_);
-  void* bufs[] = {d_res_nodes_, d_res_dist_, d_res_cnt_, d_res_status_, d_q_};
-  for (void* b : bufs)
-    if (b) fvdb_dev_free(ctx_, b);
+  for (uint32_t i = 0; i < kSlots; ++i) {
+    DevSlot& sl = slots_[i];
+    fvdb_ctx* c = sl.ctx ? sl.ctx : ctx_;
+    if (sl.d_nodes) fvdb_dev_free(c, sl.d_nodes);  // the other pointers are carved out of these two blocks
+    if (sl.h_nodes) fvdb_host_free(c, sl.h_nodes);
+    if (i > 0 && sl.ctx) fvdb_ctx_destroy(sl.ctx);
+  }
+  if (d_q_) fvdb_dev_free(ctx_, d_q_);
   for (auto& ln : lanes_)
     if (ln.sc) fvdb_scorer_destroy(ln.sc);
   if (scorer_) fvdb_scorer_destroy(scorer_);
@@ -537,36 +542,54 @@ bool HNSWIndex::device_path_ok(uint32_t ef) const {
   return device_traversal_ && !env_off && maxdeg + 1 <= 64 && ef <= 4096;
 }
 
-// whole batch in one launch (asynchronous on the context's stream)
-int HNSWIndex::device_launch(const float* q_dev, uint32_t B, uint32_t k, uint32_t ef) {
+// whole batch in one launch, results copied to pinned host memory — all asynchronous on the slot's stream
+int HNSWIndex::device_launch(const float* q_dev, uint32_t B, uint32_t k, uint32_t ef, uint32_t slot) {
+  if (slot >= kSlots) return FVDB_E_INVALID;
   int rc = sync_graph();
   if (rc) return rc;
-  const uint64_t need = (uint64_t)B * std::max<uint32_t>(k, 1);
-  if (need > d_res_cap_) {
-    void** bufs[] = {&d_res_nodes_, &d_res_dist_, &d_res_cnt_, &d_res_status_};
-    for (void** b : bufs) {
-      if (*b) fvdb_dev_free(ctx_, *b);
-      *b = nullptr;
+  DevSlot& sl = slots_[slot];
+  if (!sl.ctx) {
+    if (slot == 0) {
+      sl.ctx = ctx_;
+    } else {
+      rc = fvdb_ctx_create(fvdb_ctx_device(ctx_), &sl.ctx);
+      if (rc) return rc;
     }
-    d_res_cap_ = 0;
-    if (fvdb_dev_alloc(ctx_, need * 4, &d_res_nodes_) || fvdb_dev_alloc(ctx_, need * 4, &d_res_dist_) ||
-        fvdb_dev_alloc(ctx_, need * 4, &d_res_cnt_) || fvdb_dev_alloc(ctx_, need * 4, &d_res_status_))
-      return FVDB_E_OOM;
-    d_res_cap_ = need;
   }
-  return fvdb_graph_search_dev(graph_, q_dev, B, k, ef, (uint32_t*)d_res_nodes_, (float*)d_res_dist_,
-                               (uint32_t*)d_res_cnt_, (uint32_t*)d_res_status_);
+  // one device block and one pinned block per slot: [nodes B*k | dist B*k | counts B | status B] -> a single copy
+  const uint64_t need = (uint64_t)B * std::max<uint32_t>(k, 1);
+  const uint64_t words = 2 * need + 2 * (uint64_t)B;
+  if (words > sl.cap) {
+    if (sl.d_nodes) fvdb_dev_free(sl.ctx, sl.d_nodes);
+    if (sl.h_nodes) fvdb_host_free(sl.ctx, sl.h_nodes);
+    sl.d_nodes = sl.h_nodes = nullptr;
+    sl.cap = 0;
+    if (fvdb_dev_alloc(sl.ctx, words * 4, &sl.d_nodes) || fvdb_host_alloc(sl.ctx, words * 4, &sl.h_nodes)) return FVDB_E_OOM;
+    sl.cap = words;
+  }
+  auto carve = [&](void* base, void*& dist, void*& cnt, void*& status) {
+    dist = (uint32_t*)base + need;
+    cnt = (uint32_t*)base + 2 * need;
+    status = (uint32_t*)base + 2 * need + B;
+  };
+  carve(sl.d_nodes, sl.d_dist, sl.d_cnt, sl.d_status);
+  carve(sl.h_nodes, sl.h_dist, sl.h_cnt, sl.h_status);
+  rc = fvdb_graph_search_dev_slot(graph_, slot == 0 ? nullptr : sl.ctx, slot, q_dev, B, k, ef, (uint32_t*)sl.d_nodes,
+                                  (float*)sl.d_dist, (uint32_t*)sl.d_cnt, (uint32_t*)sl.d_status);
+  if (!rc) rc = fvdb_dev_download_async(sl.ctx, sl.h_nodes, sl.d_nodes, (size_t)words * 4);
+  return rc;
 }
 
-// wait + fetch; queries the kernel could not finish on chip are listed in `failed`
+// wait + translate; queries the kernel could not finish on chip are listed in `failed`
 int HNSWIndex::device_collect(uint32_t B, uint32_t k, uint64_t* ids, float* dist, uint32_t* counts,
-                              std::vector<uint32_t>& failed) {
-  std::vector<uint32_t> nodes((size_t)B * k), status(B);
-  int rc = fvdb_dev_download(ctx_, nodes.data(), d_res_nodes_, (size_t)B * k * 4);
-  if (!rc) rc = fvdb_dev_download(ctx_, dist, d_res_dist_, (size_t)B * k * 4);
-  if (!rc) rc = fvdb_dev_download(ctx_, counts, d_res_cnt_, (size_t)B * 4);
-  if (!rc) rc = fvdb_dev_download(ctx_, status.data(), d_res_status_, (size_t)B * 4);
+                              std::vector<uint32_t>& failed, uint32_t slot) {
+  DevSlot& sl = slots_[slot];
+  int rc = fvdb_ctx_synchronize(sl.ctx);
   if (rc) return rc;
+  const uint32_t* nodes = (const uint32_t*)sl.h_nodes;
+  const uint32_t* status = (const uint32_t*)sl.h_status;
+  std::memcpy(dist, sl.h_dist, (size_t)B * k * 4);
+  std::memcpy(counts, sl.h_cnt, (size_t)B * 4);
   for (uint32_t b = 0; b < B; ++b) {
     if (status[b]) {
       failed.push_back(b);
@@ -608,17 +631,18 @@ int HNSWIndex::finish_failed(const float* q, bool q_on_device, uint32_t dim, uin
   return FVDB_OK;
 }
 
-bool HNSWIndex::search_dev_begin(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, int* rc) {
+bool HNSWIndex::search_dev_begin(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, int* rc,
+                                 uint32_t slot) {
   *rc = FVDB_OK;
   if (!has_entry_ || B == 0 || k == 0 || (has_dim_ && dim != dim_) || !device_path_ok(ef)) return false;
-  *rc = device_launch(q_dev, B, k, ef);
+  *rc = device_launch(q_dev, B, k, ef, slot);
   return *rc == FVDB_OK;
 }
 
 int HNSWIndex::search_dev_end(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids,
-                              float* dist, uint32_t* counts) {
+                              float* dist, uint32_t* counts, uint32_t slot) {
   std::vector<uint32_t> failed;
-  int rc = device_collect(B, k, ids, dist, counts, failed);
+  int rc = device_collect(B, k, ids, dist, counts, failed, slot);
   if (rc) return rc;
   return finish_failed(q_dev, true, dim, k, ef, ids, dist, counts, failed);
 }
@@ -648,10 +672,10 @@ int HNSWIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint32_
     if (rc) return rc;
     qd = (const float*)d_q_;
   }
-  int rc = device_launch(qd, B, k, ef);
+  int rc = device_launch(qd, B, k, ef, 0);
   if (rc) return rc;
   std::vector<uint32_t> failed;
-  rc = device_collect(B, k, ids, dist, counts, failed);
+  rc = device_collect(B, k, ids, dist, counts, failed, 0);
   if (rc) return rc;
   return finish_failed(q, q_on_device, dim, k, ef, ids, dist, counts, failed);
 }

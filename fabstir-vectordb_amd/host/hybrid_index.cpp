@@ -15,9 +15,11 @@ HybridIndex::HybridIndex(fvdb_ctx* ctx_ivf, fvdb_ctx* ctx_hnsw, const HybridConf
 }
 
 HybridIndex::~HybridIndex() {
-  if (d_hid_) fvdb_dev_free(ctx_ivf_, d_hid_);
-  if (d_hd_) fvdb_dev_free(ctx_ivf_, d_hd_);
-  if (d_hc_) fvdb_dev_free(ctx_ivf_, d_hc_);
+  for (Slot& sl : slots_) {
+    if (sl.d_hid) fvdb_dev_free(ctx_ivf_, sl.d_hid);  // the other pointers are carved out of these two blocks
+    if (sl.h_hid) fvdb_host_free(ctx_ivf_, sl.h_hid);
+    if (sl.ivf_done) fvdb_event_destroy(sl.ivf_done);
+  }
   delete recent_;
   delete historical_;
 }
@@ -234,8 +236,127 @@ int HybridIndex::search_dev(const float* q_dev, uint32_t B, uint32_t dim, const 
   return search_impl(q_dev, true, B, dim, cfg, now, ids, dist, counts);
 }
 
+// stable merge of the two parts (:476-485): concatenate recent then historical, stable sort by distance, take k
+static void merge_parts(uint32_t B, uint32_t k, uint32_t rk, uint32_t hk, bool have_r, const uint64_t* rid, const float* rd,
+                        const uint32_t* rc, bool have_h, const uint64_t* hid, const float* hd, const uint32_t* hc,
+                        uint64_t* ids, float* dist, uint32_t* counts) {
+  struct R {
+    uint64_t id;
+    float d;
+  };
+  std::vector<R> all;
+  for (uint32_t b = 0; b < B; ++b) {
+    all.clear();
+    if (have_r)
+      for (uint32_t i = 0; i < rc[b]; ++i) all.push_back({rid[(size_t)b * rk + i], rd[(size_t)b * rk + i]});
+    if (have_h)
+      for (uint32_t i = 0; i < hc[b]; ++i) all.push_back({hid[(size_t)b * hk + i], hd[(size_t)b * hk + i]});
+    std::stable_sort(all.begin(), all.end(), [](const R& a, const R& c) { return a.d < c.d; });  // :482
+    if (all.size() > k) all.resize(k);
+    for (size_t i = 0; i < all.size(); ++i) {
+      ids[(size_t)b * k + i] = all[i].id;
+      dist[(size_t)b * k + i] = all[i].d;
+    }
+    counts[b] = (uint32_t)all.size();
+  }
+}
+
+int HybridIndex::search_dev_begin(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
+                                  double now) {
+  if (slot >= kSlots) return FVDB_E_INVALID;
+  Slot& sl = slots_[slot];
+  if (sl.active) return FVDB_E_INVALID;  // the previous batch of this slot was never collected
+  sl = Slot{sl.d_hid, sl.d_hd, sl.d_hc, sl.h_hid, sl.h_hd, sl.h_hc, sl.cap, sl.ivf_done};
+  sl.q = q_dev;
+  sl.B = B;
+  sl.dim = dim;
+  sl.k = (uint32_t)cfg.k;
+  sl.rk = (uint32_t)(cfg.recent_k > 0 ? cfg.recent_k : cfg.k);
+  sl.hk = (uint32_t)(cfg.historical_k > 0 ? cfg.historical_k : cfg.k);
+  sl.ef = (uint32_t)cfg.hnsw_ef;
+  sl.recent = cfg.search_recent;
+  sl.active = true;
+  if (!initialized_ || B == 0 || sl.k == 0) return FVDB_OK;
+  if (cfg_.auto_migrate) migrate_with_threshold(cfg_.recent_threshold_s, now);
+  if (cfg.search_recent) {
+    // the graph walk is latency-bound (one wave per query): enqueue it FIRST so that the list scan launched
+    // next fills the rest of every SIMD and the two run concurrently
+    int rcb = 0;
+    sl.hnsw_in_flight = recent_->search_dev_begin(q_dev, B, dim, sl.rk, sl.ef, &rcb, slot);
+  }
+  if (cfg.search_historical && ivf_trained_) {
+    // one device block and one pinned block per slot: [ids B*hk u64 | dist B*hk f32 | counts B u32] -> a single copy
+    const uint64_t need = (uint64_t)B * sl.hk;
+    const uint64_t bytes = need * 12 + (uint64_t)B * 4;
+    if (bytes > sl.cap) {
+      if (sl.d_hid) fvdb_dev_free(ctx_ivf_, sl.d_hid);
+      if (sl.h_hid) fvdb_host_free(ctx_ivf_, sl.h_hid);
+      sl.d_hid = sl.h_hid = nullptr;
+      sl.cap = 0;
+      if (fvdb_dev_alloc(ctx_ivf_, bytes, &sl.d_hid) || fvdb_host_alloc(ctx_ivf_, bytes, &sl.h_hid)) return FVDB_E_OOM;
+      sl.cap = bytes;
+    }
+    sl.d_hd = (char*)sl.d_hid + need * 8;
+    sl.d_hc = (char*)sl.d_hid + need * 12;
+    sl.h_hd = (char*)sl.h_hid + need * 8;
+    sl.h_hc = (char*)sl.h_hid + need * 12;
+    if (!sl.ivf_done && fvdb_event_create(ctx_ivf_, &sl.ivf_done)) return FVDB_E_HIP;
+    sl.ivf_in_flight = historical_->search_dev(q_dev, B, dim, sl.hk, (uint32_t)cfg.ivf_n_probe, (uint64_t*)sl.d_hid,
+                                               (float*)sl.d_hd, (uint32_t*)sl.d_hc) == FVDB_OK;
+    if (sl.ivf_in_flight) {
+      // result copies ride the IVF stream right behind the chain (before the next batch's chain), then the event
+      if (fvdb_dev_download_async(ctx_ivf_, sl.h_hid, sl.d_hid, (size_t)bytes) || fvdb_event_record(ctx_ivf_, sl.ivf_done))
+        return FVDB_E_HIP;
+    }
+  }
+  return FVDB_OK;
+}
+
+int HybridIndex::search_dev_end(uint32_t slot, uint64_t* ids, float* dist, uint32_t* counts) {
+  if (slot >= kSlots || !slots_[slot].active) return FVDB_E_INVALID;
+  Slot& sl = slots_[slot];
+  sl.active = false;
+  const uint32_t B = sl.B, k = sl.k;
+  for (uint32_t b = 0; b < B; ++b) counts[b] = 0;
+  for (size_t i = 0; i < (size_t)B * k; ++i) {
+    ids[i] = FVDB_NO_ID;
+    dist[i] = __builtin_huge_valf();
+  }
+  if (!initialized_ || B == 0 || k == 0) return FVDB_OK;
+  std::vector<uint64_t> rid;
+  std::vector<float> rd;
+  std::vector<uint32_t> rc_(B, 0);
+  bool have_r = false, have_h = false;
+  if (sl.recent) {
+    rid.resize((size_t)B * sl.rk);
+    rd.resize((size_t)B * sl.rk);
+    int rc2 = sl.hnsw_in_flight
+                  ? recent_->search_dev_end(sl.q, B, sl.dim, sl.rk, sl.ef, rid.data(), rd.data(), rc_.data(), slot)
+                  : recent_->search_dev(sl.q, B, sl.dim, sl.rk, sl.ef, rid.data(), rd.data(), rc_.data());
+    have_r = rc2 == FVDB_OK;
+  }
+  if (sl.ivf_in_flight) {
+    have_h = fvdb_event_wait(ctx_ivf_, sl.ivf_done) == FVDB_OK;
+    bool busy = false;
+    for (const Slot& o : slots_) busy = busy || o.active;
+    if (!busy) fvdb_ivf_profile_collect(historical_->device());  // stage timing only makes sense one batch at a time
+  }
+  merge_parts(B, k, sl.rk, sl.hk, have_r, rid.data(), rd.data(), rc_.data(), have_h, (const uint64_t*)sl.h_hid,
+              (const float*)sl.h_hd, (const uint32_t*)sl.h_hc, ids, dist, counts);
+  return FVDB_OK;
+}
+
 int HybridIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
                              double now, uint64_t* ids, float* dist, uint32_t* counts) {
+  if (q_on_device) {
+    int rc0 = search_dev_begin(0, q, B, dim, cfg, now);
+    if (rc0) {
+      slots_[0].active = false;
+      return rc0;
+    }
+    return search_dev_end(0, ids, dist, counts);
+  }
+  // host-resident queries: the two parts one after the other (each stages its own copy of the batch)
   const uint32_t k = (uint32_t)cfg.k;
   for (uint32_t b = 0; b < B; ++b) counts[b] = 0;
   for (size_t i = 0; i < (size_t)B * k; ++i) {
@@ -250,78 +371,18 @@ int HybridIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint3
   std::vector<float> rd, hd;
   std::vector<uint32_t> rc_(B, 0), hc(B, 0);
   bool have_r = false, have_h = false;
-  static const bool dbg = getenv("FVDB_DEBUG") != nullptr;
-  if (dbg) fprintf(stderr, "[hybrid] search B=%u k=%u dev=%d\n", B, k, (int)q_on_device);
-  bool ivf_in_flight = false, hnsw_in_flight = false;
-  if (cfg.search_recent) {
-    rid.resize((size_t)B * rk);
-    rd.resize((size_t)B * rk);
-    if (q_on_device) {
-      // the graph walk is latency-bound (one wave per query): enqueue it FIRST so that the VALU-bound
-      // list scan launched next fills the rest of every SIMD and the two run concurrently
-      int rcb = 0;
-      hnsw_in_flight = recent_->search_dev_begin(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, &rcb);
-    }
-  }
   if (cfg.search_historical && ivf_trained_) {
     hid.resize((size_t)B * hk);
     hd.resize((size_t)B * hk);
-    if (!q_on_device) {
-      have_h = historical_->search(q, B, dim, hk, (uint32_t)cfg.ivf_n_probe, hid.data(), hd.data(), hc.data()) == FVDB_OK;
-    } else {
-      const uint64_t need = (uint64_t)B * hk;
-      if (need > d_cap_) {
-        if (d_hid_) fvdb_dev_free(ctx_ivf_, d_hid_);
-        if (d_hd_) fvdb_dev_free(ctx_ivf_, d_hd_);
-        if (d_hc_) fvdb_dev_free(ctx_ivf_, d_hc_);
-        d_hid_ = d_hd_ = d_hc_ = nullptr;
-        d_cap_ = 0;
-        if (fvdb_dev_alloc(ctx_ivf_, need * 8, &d_hid_) || fvdb_dev_alloc(ctx_ivf_, need * 4, &d_hd_) ||
-            fvdb_dev_alloc(ctx_ivf_, need * 4, &d_hc_))
-          return FVDB_E_OOM;
-        d_cap_ = need;
-      }
-      ivf_in_flight = historical_->search_dev(q, B, dim, hk, (uint32_t)cfg.ivf_n_probe, (uint64_t*)d_hid_,
-                                              (float*)d_hd_, (uint32_t*)d_hc_) == FVDB_OK;
-    }
+    have_h = historical_->search(q, B, dim, hk, (uint32_t)cfg.ivf_n_probe, hid.data(), hd.data(), hc.data()) == FVDB_OK;
   }
-  if (dbg) fprintf(stderr, "[hybrid] enqueued (ivf in flight=%d, hnsw in flight=%d)\n", (int)ivf_in_flight, (int)hnsw_in_flight);
   if (cfg.search_recent) {
-    int rc2;
-    if (hnsw_in_flight)
-      rc2 = recent_->search_dev_end(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, rid.data(), rd.data(), rc_.data());
-    else
-      rc2 = q_on_device ? recent_->search_dev(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, rid.data(), rd.data(), rc_.data())
-                        : recent_->search(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, rid.data(), rd.data(), rc_.data());
-    have_r = rc2 == FVDB_OK;
+    rid.resize((size_t)B * rk);
+    rd.resize((size_t)B * rk);
+    have_r = recent_->search(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, rid.data(), rd.data(), rc_.data()) == FVDB_OK;
   }
-  if (dbg) fprintf(stderr, "[hybrid] hnsw done\n");
-  if (ivf_in_flight) {
-    have_h = fvdb_dev_download(ctx_ivf_, hid.data(), d_hid_, (size_t)B * hk * 8) == FVDB_OK &&
-             fvdb_dev_download(ctx_ivf_, hd.data(), d_hd_, (size_t)B * hk * 4) == FVDB_OK &&
-             fvdb_dev_download(ctx_ivf_, hc.data(), d_hc_, (size_t)B * 4) == FVDB_OK;
-    fvdb_ivf_profile_collect(historical_->device());
-  }
-  if (dbg) fprintf(stderr, "[hybrid] ivf downloaded\n");
-  struct R {
-    uint64_t id;
-    float d;
-  };
-  std::vector<R> all;
-  for (uint32_t b = 0; b < B; ++b) {
-    all.clear();
-    if (have_r)
-      for (uint32_t i = 0; i < rc_[b]; ++i) all.push_back({rid[(size_t)b * rk + i], rd[(size_t)b * rk + i]});
-    if (have_h)
-      for (uint32_t i = 0; i < hc[b]; ++i) all.push_back({hid[(size_t)b * hk + i], hd[(size_t)b * hk + i]});
-    std::stable_sort(all.begin(), all.end(), [](const R& a, const R& c) { return a.d < c.d; });  // :482
-    if (all.size() > k) all.resize(k);
-    for (size_t i = 0; i < all.size(); ++i) {
-      ids[(size_t)b * k + i] = all[i].id;
-      dist[(size_t)b * k + i] = all[i].d;
-    }
-    counts[b] = (uint32_t)all.size();
-  }
+  merge_parts(B, k, rk, hk, have_r, rid.data(), rd.data(), rc_.data(), have_h, hid.data(), hd.data(), hc.data(), ids, dist,
+              counts);
   return FVDB_OK;
 }
 

@@ -66,7 +66,7 @@ HOST_SIGNATURES = {
     "fvh_hnsw_set_device_traversal": (None, [vp, i32]),
     "fvh_hnsw_device_traversal": (i32, [vp]),
     "fvh_hnsw_device_fallbacks": (u64, [vp]),
-    "fvh_hnsw_graph_kernel_times": (i32, [vp, f32p, u32p]),
+    "fvh_hnsw_graph_kernel_times": (i32, [vp, f32p, u32p, u64p, u64p]),
     "fvh_hybrid_new": (vp, [vp, vp, dbl, u64, i32, u64, u32, u32, u32, u64, u32, u32, u32, u32, u64]),
     "fvh_hybrid_free": (None, [vp]),
     "fvh_hybrid_initialize": (i32, [vp, f32p, u64, u32]),
@@ -76,6 +76,8 @@ HOST_SIGNATURES = {
     "fvh_hybrid_bulk_insert_sharded": (i32, [vp, u64p, f32p, u64, u32, f64p, dbl, u32, u32, u32p]),
     "fvh_hybrid_search": (i32, [vp, f32p, u32, u32, u64, u64, u64, i32, i32, u64, u64, dbl, u64p, f32p, u32p]),
     "fvh_hybrid_search_dev": (i32, [vp, vp, u32, u32, u64, u64, u64, i32, i32, u64, u64, dbl, u64p, f32p, u32p]),
+    "fvh_hybrid_search_dev_begin": (i32, [vp, u32, vp, u32, u32, u64, u64, u64, i32, i32, u64, u64, dbl]),
+    "fvh_hybrid_search_dev_end": (i32, [vp, u32, u64p, f32p, u32p]),
     "fvh_hnsw_search_dev": (i32, [vp, vp, u32, u32, u32, u32, u64p, f32p, u32p]),
     "fvh_hybrid_delete": (i32, [vp, u64, dbl]),
     "fvh_hybrid_migrate": (u64, [vp, dbl, dbl]),
@@ -379,10 +381,11 @@ class HNSWIndex(_Base):
         return int(self.lib.fvh_hnsw_device_fallbacks(self.h))
 
     def graph_kernel_times(self):
-        """(summed ms, launches) of the device traversal kernel since the last call (needs ctx profiling on)."""
-        ms, n = C.c_float(0), C.c_uint32(0)
-        self.lib.fvh_hnsw_graph_kernel_times(self.h, C.byref(ms), C.byref(n))
-        return float(ms.value), int(n.value)
+        """(summed ms, launches timed, rows scored, hops) of the device traversal kernel since the last call
+        (timings need ctx profiling on; the counters are always kept)."""
+        ms, n, rows, hops = C.c_float(0), C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+        self.lib.fvh_hnsw_graph_kernel_times(self.h, C.byref(ms), C.byref(n), C.byref(rows), C.byref(hops))
+        return float(ms.value), int(n.value), int(rows.value), int(hops.value)
 
 
 class HybridIndex(_Base):
@@ -467,6 +470,28 @@ class HybridIndex(_Base):
         self._check(self.lib.fvh_hybrid_search_dev(self.h, q_dev, B, dim, k, hnsw_ef, ivf_n_probe, int(search_recent),
                                                    int(search_historical), recent_k, historical_k, float(now),
                                                    _ptr(ids, u64p), _ptr(ds, f32p), _ptr(cnt, u32p)))
+        return SearchResults(ids, ds, cnt)
+
+    SLOTS = 4
+
+    def search_dev_begin(self, slot, q_dev, B, k, now=0.0, hnsw_ef=50, ivf_n_probe=10, search_recent=True,
+                         search_historical=True, recent_k=0, historical_k=0, dim=None):
+        """Enqueue a batch search in `slot` (0..SLOTS-1) and return at once; several slots may be in flight together
+        (the graph walk of one batch uses one wavefront per SIMD, so a second batch's walk runs beside it).  The
+        query buffer must stay valid until search_dev_end(slot); no inserts/deletes in between."""
+        self._check(self.lib.fvh_hybrid_search_dev_begin(self.h, slot, q_dev, B, dim, k, hnsw_ef, ivf_n_probe,
+                                                         int(search_recent), int(search_historical), recent_k,
+                                                         historical_k, float(now)))
+        self._inflight = getattr(self, "_inflight", {})
+        self._inflight[slot] = (B, k)
+
+    def search_dev_end(self, slot):
+        """Wait for the batch of `slot` and return its SearchResults."""
+        B, k = self._inflight.pop(slot)
+        ids = np.empty((B, max(k, 1)), np.uint64)
+        ds = np.empty((B, max(k, 1)), np.float32)
+        cnt = np.zeros(B, np.uint32)
+        self._check(self.lib.fvh_hybrid_search_dev_end(self.h, slot, _ptr(ids, u64p), _ptr(ds, f32p), _ptr(cnt, u32p)))
         return SearchResults(ids, ds, cnt)
 
     def delete(self, id, now=0.0):

@@ -64,6 +64,7 @@ typedef struct fvdb_store fvdb_store; /* row-major vector store for gathered can
 int fvdb_ctx_create(int device, fvdb_ctx** out);
 void fvdb_ctx_destroy(fvdb_ctx* ctx);
 int fvdb_ctx_synchronize(fvdb_ctx* ctx);
+int fvdb_ctx_device(fvdb_ctx* ctx); /* the device ordinal the context was created on */
 void* fvdb_ctx_stream(fvdb_ctx* ctx);          /* hipStream_t, for callers that interleave work */
 const char* fvdb_last_error(fvdb_ctx* ctx);    /* message of the last failing call on ctx */
 const char* fvdb_version(void);
@@ -72,6 +73,16 @@ int fvdb_dev_alloc(fvdb_ctx* ctx, size_t bytes, void** out);
 int fvdb_dev_free(fvdb_ctx* ctx, void* p);
 int fvdb_dev_upload(fvdb_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int fvdb_dev_download(fvdb_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* Pieces for keeping more than one batch in flight: pinned host memory, a copy that does not wait, and events
+ * recorded on a context's stream (fvdb_event_wait blocks the host until the work recorded before it is done). */
+int fvdb_host_alloc(fvdb_ctx* ctx, size_t bytes, void** out);
+void fvdb_host_free(fvdb_ctx* ctx, void* p);
+int fvdb_dev_download_async(fvdb_ctx* ctx, void* dst_pinned, const void* src_dev, size_t bytes);
+typedef struct fvdb_event fvdb_event;
+int fvdb_event_create(fvdb_ctx* ctx, fvdb_event** out);
+void fvdb_event_destroy(fvdb_event* e);
+int fvdb_event_record(fvdb_ctx* ctx, fvdb_event* e);
+int fvdb_event_wait(fvdb_ctx* ctx, fvdb_event* e);
 /* Stream-ordered timing of the region between the two calls (HIP events on ctx's stream). */
 int fvdb_timer_start(fvdb_ctx* ctx);
 int fvdb_timer_stop_ms(fvdb_ctx* ctx, float* out_ms);
@@ -250,9 +261,15 @@ int fvdb_graph_set_deleted(fvdb_graph* g, uint32_t node, int deleted);
 int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_t k, uint32_t ef,
                           uint32_t* out_nodes_dev, float* out_dist_dev, uint32_t* out_counts_dev,
                           uint32_t* out_status_dev);
+/* Same on the stream of context `on` (NULL = the store's context), with the slot-th (0..3) set of per-batch
+ * traversal state: searches in different slots and on different contexts may be in flight together. */
+int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t k,
+                               uint32_t ef, uint32_t* out_nodes_dev, float* out_dist_dev, uint32_t* out_counts_dev,
+                               uint32_t* out_status_dev);
 /* With profiling on (fvdb_ctx_set_profiling): summed duration (HIP events on the launch stream) of the last
- * <= 64 launches of the traversal kernel since the previous call, and how many were summed.  Synchronises. */
-int fvdb_graph_kernel_times(fvdb_graph* g, float* ms_sum, uint32_t* launches);
+ * <= 64 launches of the traversal kernel since the previous call, and how many were summed; and (always) the
+ * rows scored and hops taken by all queries since the previous call (either may be NULL).  Synchronises. */
+int fvdb_graph_kernel_times(fvdb_graph* g, float* ms_sum, uint32_t* launches, uint64_t* rows_scored, uint64_t* hops);
 
 #ifdef __cplusplus
 }

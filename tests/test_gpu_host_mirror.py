@@ -369,3 +369,42 @@ def test_hybrid_parity_with_oracle(fv, ctx):
     assert (g.recent_count(), g.historical_count()) == (o.recent_count(), o.historical_count())
     assert_same_results(rg, oi, od, oc)
     assert any(len(set(rg.ids[b, : rg.counts[b]].tolist())) < rg.counts[b] for b in range(len(rg)))
+
+
+def test_hybrid_batches_in_flight_match_one_at_a_time(fv, ctx):
+    # search_dev_begin / search_dev_end: several batches in flight (graph walks on their own streams, IVF chains
+    # queued on one) give, slot by slot, exactly the results of the one-at-a-time search and of the oracle
+    n, d, nlist = 4000, 64, 16
+    x = mixture(n, d, n_comp=16, seed=91)
+    cents = x[:nlist].copy()
+    now = 1000 * DAY
+    rng = np.random.default_rng(2)
+    ages = np.where(rng.random(n) < 0.3, 1 * DAY, 30 * DAY)
+    levels = orc.rng_levels(78, n)
+    kw = dict(max_connections=8, max_connections_layer_0=16, ef_construction=40, n_clusters=nlist, n_probe=4)
+    g, o = fv.HybridIndex(ctx, **kw), orc.HybridIndex(**kw)
+    g.set_ivf_centroids(cents)
+    o.set_ivf_centroids(cents)
+    for i in range(n):
+        g.insert_with_timestamp(i, x[i], now - ages[i], now, int(levels[i]))
+        o.insert_with_timestamp(i, x[i], now - ages[i], now, int(levels[i]))
+    batches = [mixture(64, d, n_comp=16, seed=200 + j) for j in range(7)]
+    qdev = [g.ctx.upload(b) for b in batches]
+    want = [g.search_dev(qdev[j], 64, 10, now=now, hnsw_ef=30, ivf_n_probe=4, dim=d) for j in range(len(batches))]
+    for depth in (2, 3, 4):
+        got = [None] * len(batches)
+        for j in range(len(batches)):
+            if j >= depth:
+                got[j - depth] = g.search_dev_end((j - depth) % depth)
+            g.search_dev_begin(j % depth, qdev[j], 64, 10, now=now, hnsw_ef=30, ivf_n_probe=4, dim=d)
+        for j in range(max(len(batches) - depth, 0), len(batches)):
+            got[j] = g.search_dev_end(j % depth)
+        for a, b in zip(got, want):
+            assert np.array_equal(a.counts, b.counts) and np.array_equal(a.ids, b.ids)
+            assert np.array_equal(bits(a.distances), bits(b.distances))
+    # and the oracle, on the first batch
+    r = want[0]
+    for b in range(64):
+        ro = o.search(batches[0][b], 10, now=now, hnsw_ef=30, ivf_n_probe=4)
+        assert r.counts[b] == len(ro) and np.array_equal(r.ids[b, : len(ro)], ro.ids)
+        assert np.array_equal(bits(r.distances[b, : len(ro)]), bits(np.asarray(ro.distances, np.float32)))

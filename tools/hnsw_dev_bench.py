@@ -6,7 +6,7 @@ import fvdb_import
 from bench import Generator
 fv = fvdb_import.load()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000
-B, d, k, ef = 1024, 384, 10, int(sys.argv[2]) if len(sys.argv) > 2 else 50
+B, d, k, ef = (int(sys.argv[3]) if len(sys.argv) > 3 else 1024), 384, 10, int(sys.argv[2]) if len(sys.argv) > 2 else 50
 gen = Generator(d=d)
 x = np.concatenate([gen.rows(10000, s) for s in range(n // 10000)])
 q = gen.rows(B, 10_000_000)
@@ -14,7 +14,7 @@ ctx = fv.Context(0)
 h = fv.HNSWIndex(ctx, 16, 32, 200, seed=11)
 t = time.time(); h.bulk_build(np.arange(n, dtype=np.uint64), x); print(f"bulk build {time.time()-t:.1f}s", flush=True)
 qd = ctx.upload(q)
-for mode in (True, False):
+for mode in ((True, False) if len(sys.argv) <= 3 else (True,)):
     h.set_device_traversal(mode)
     for _ in range(2): h.search_dev(qd, B, d, k, ef)
     t = time.perf_counter(); R = 5
