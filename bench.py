@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--recall-target", type=float, default=0.95)
     ap.add_argument("--train-sample", type=int, default=100_000)
     ap.add_argument("--query-batches", type=int, default=4)
-    ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hnsw-traversal", choices=["device", "host"], default="device",
                     help="device: the layered walk runs on the GPU (one launch per batch); host: on the host with one "
@@ -126,6 +126,18 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL prints a version banner on stdout at its first collective; stdout must carry ONE JSON line, so the
+        # first collective runs with fd 1 pointed at stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     import fvdb_import
     fv = fvdb_import.load()
