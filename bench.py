@@ -103,7 +103,9 @@ def main():
                     help="device: the layered walk runs on the GPU (one launch per batch); host: on the host with one "
                          "candidate-scoring launch per hop (the north_star's split).  Identical results.")
     ap.add_argument("--compare-host-walk", type=int, default=5, help="extra steps timed with the host walk (0 = skip)")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--parts", choices=["both", "recent", "historical"], default="both",
+                    help="development aid: time only the HNSW or only the IVF part of the hybrid search (recall is then meaningless)")
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="batches in flight during the timed region (1 = each step collected before the next is enqueued)")
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--spread", type=float, default=1.5)
@@ -224,8 +226,33 @@ def main():
     log(f"operating point: nprobe={nprobe} ef={ef}")
 
     # ---- timed region ----
+    depth = max(1, min(args.in_flight, 4)) if sharded is None else 1
+    kw = dict(now=now, hnsw_ef=ef, ivf_n_probe=nprobe, dim=d, search_recent=args.parts != "historical",
+              search_historical=args.parts != "recent")
+
+    def pipelined(nsteps):
+        """nsteps searches with up to `depth` batches in flight; returns the last result and the host time spent
+        enqueuing / collecting."""
+        t_begin = t_end = 0.0
+        res = None
+        for i in range(nsteps):
+            ta = time.perf_counter()
+            hyb.search_dev_begin(i % depth, qdev[i % nb], B, k, **kw)  # slot i % depth was collected one iteration ago
+            tb = time.perf_counter()
+            if i >= depth - 1:
+                res = hyb.search_dev_end((i - depth + 1) % depth)
+            t_begin += tb - ta
+            t_end += time.perf_counter() - tb
+        for i in range(max(nsteps - depth + 1, 0), nsteps):
+            ta = time.perf_counter()
+            res = hyb.search_dev_end(i % depth)
+            t_end += time.perf_counter() - ta
+        return res, t_begin, t_end
+
     for i in range(args.warmup):
         run(i, nprobe, ef)
+    if depth > 1:
+        pipelined(max(args.warmup, 2 * depth))  # every slot has its stream, buffers and traversal state before timing
     log("warmup done")
     ctx_ivf.set_profiling(2)
     ctx_hnsw.set_profiling(2)     # HIP events around the traversal kernel (its own stream)
@@ -238,30 +265,16 @@ def main():
         torch.cuda.synchronize()
     ctx_ivf.synchronize()
     ctx_hnsw.synchronize()
-    depth = max(1, min(args.in_flight, 4)) if sharded is None else 1
     t0 = time.perf_counter()
     last = None
     if depth == 1:
         for i in range(args.steps):
             last = run(i, nprobe, ef)
     else:
-        # `depth` batches in flight: step i is enqueued (graph walk on its own stream, IVF chain behind the previous
-        # batch's on the IVF stream) before step i - depth is collected and merged on the host.  Every step's
-        # results are complete, on the host, inside the timed region.
-        t_begin = t_end = 0.0
-        for i in range(args.steps):
-            if i >= depth:
-                ta = time.perf_counter()
-                last = hyb.search_dev_end((i - depth) % depth)
-                t_end += time.perf_counter() - ta
-            ta = time.perf_counter()
-            hyb.search_dev_begin(i % depth, qdev[i % nb], B, k, now=now, hnsw_ef=ef, ivf_n_probe=nprobe, dim=d)
-            t_begin += time.perf_counter() - ta
-        for i in range(max(args.steps - depth, 0), args.steps):
-            ta = time.perf_counter()
-            last = hyb.search_dev_end(i % depth)
-            t_end += time.perf_counter() - ta
-        log(f"host time per step: enqueue {t_begin / args.steps * 1e3:.3f} ms, collect+merge (incl. waiting) {t_end / args.steps * 1e3:.3f} ms")
+        # up to `depth` batches in flight: step i is enqueued (graph walk on its own stream, IVF chain behind the
+        # previous batch's on the IVF stream) before step i - depth + 1 is collected and merged on the host.  Every
+        # step's results are complete, on the host, inside the timed region.
+        last, t_begin, t_end = pipelined(args.steps)
     ctx_ivf.synchronize()
     ctx_hnsw.synchronize()
     if dist is not None:
@@ -269,6 +282,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {elapsed:.3f}s")
+    if depth > 1:
+        log(f"host time per step: enqueue {t_begin / args.steps * 1e3:.3f} ms, collect+merge (incl. waiting) {t_end / args.steps * 1e3:.3f} ms")
     if dist is not None:
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
