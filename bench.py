@@ -10,9 +10,10 @@ region starts; results return to host memory (the reference API returns them to 
 
   python bench.py --gpus N --steps K --warmup W
 N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`:
-IVF lists are sharded over the ranks (every rank scans the probed lists it owns for ALL queries,
-per-rank partial top-k are all-gathered over RCCL and merged by key), the HNSW graph is replicated
-and its queries are split over the ranks; total work is fixed => "scaling": "strong".
+every rank brings its own batch of queries per step (weak scaling); IVF lists are sharded over the ranks (the
+query batches are all-gathered, every rank scans the probed lists it owns for ALL queries, the per-rank partial
+top-k are all-gathered over RCCL and merged by key on the rank that owns the query), the HNSW graph is replicated
+and each rank searches it for its own queries.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
 "roofline" (dominant kernel = the list-scan kernel, timed with HIP events on its stream) and
@@ -126,8 +127,10 @@ def main():
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        backend = os.environ.get("FVDB_DIST_BACKEND", "nccl")  # "gloo": rehearsal of several ranks on ONE GPU
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
         # RCCL prints a version banner on stdout at its first collective; stdout must carry ONE JSON line, so the
         # first collective runs with fd 1 pointed at stderr
         sys.stdout.flush()
@@ -157,7 +160,8 @@ def main():
     is_recent = r.random(N) < args.recent_frac
     ts = np.where(is_recent, now - 1 * DAY, now - 30 * DAY)
     nb = max(1, args.query_batches)
-    queries = [gen.rows(B, stream=10_000_000 + i) for i in range(nb)]
+    # every rank brings its own query batches (weak scaling: world x B queries per step)
+    queries = [gen.rows(B, stream=10_000_000 + 1000 * rank + i) for i in range(nb)]
     log(f"data: {N} x {d} generated in {time.time() - t_setup:.1f}s; recent={int(is_recent.sum())}")
 
     ctx_ivf = fv.Context(local_rank)
@@ -191,13 +195,21 @@ def main():
     flat.close()
     log(f"exact ground truth: {time.time() - t0:.1f}s")
 
-    qdev = [ctx_ivf.upload(q) for q in queries]
+    qdev = [ctx_ivf.upload(q) for q in queries] if sharded is None else [sharded.upload_queries(q) for q in queries]
     hyb.hnsw().set_device_traversal(args.hnsw_traversal == "device")
 
     def run(i, nprobe, ef):
         if sharded is not None:
-            return sharded.search_dev(qdev[i % nb], queries[i % nb], B, k, now, ef, nprobe)
+            return sharded.search_dev(qdev[i % nb], B, k, now, ef, nprobe)
         return hyb.search_dev(qdev[i % nb], B, k, now=now, hnsw_ef=ef, ivf_n_probe=nprobe, dim=d)
+
+    def mean_over_ranks(v):
+        """Same value on every rank (decisions taken on it keep the ranks' collectives in lockstep)."""
+        if dist is None or world == 1:
+            return float(v)
+        t = torch.tensor([float(v)], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t.item()) / world
 
     # ---- operating point: smallest (nprobe, ef) of the sweep with recall@k >= target ----
     sweep = []
@@ -208,10 +220,11 @@ def main():
             for p_ in ([nprobe] if nprobe else [8, 16, 24, 32, 48, 64, 96, 128]):
                 p_ = min(p_, args.nlist)
                 res = run(0, p_, e_)
-                rec = recall_at_k(res.ids, res.counts, exact[0], k)
+                rec = mean_over_ranks(recall_at_k(res.ids, res.counts, exact[0], k))
                 if rec >= args.recall_target:  # confirm on every query batch before accepting
-                    rec = float(np.mean([rec] + [recall_at_k(*(lambda r_: (r_.ids, r_.counts))(run(i, p_, e_)), exact[i], k)
-                                                 for i in range(1, nb)]))
+                    rec = mean_over_ranks(np.mean([recall_at_k(res.ids, res.counts, exact[0], k)] +
+                                                  [recall_at_k(*(lambda r_: (r_.ids, r_.counts))(run(i, p_, e_)), exact[i], k)
+                                                   for i in range(1, nb)]))
                 sweep.append({"nprobe": p_, "ef": e_, "recall": round(rec, 4)})
                 log(f"sweep nprobe={p_} ef={e_}: recall@{k}={rec:.4f}")
                 if rec >= args.recall_target and chosen is None:
@@ -285,7 +298,7 @@ def main():
     if depth > 1:
         log(f"host time per step: enqueue {t_begin / args.steps * 1e3:.3f} ms, collect+merge (incl. waiting) {t_end / args.steps * 1e3:.3f} ms")
     if dist is not None:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     graph_ms_sum, graph_launches, graph_rows, graph_hops = hnsw.graph_kernel_times()
@@ -321,8 +334,8 @@ def main():
     for i in range(nb):
         res = run(i, nprobe, ef)
         recs.append(recall_at_k(res.ids, res.counts, exact[i], k))
-    recall = float(np.mean(recs))
-    qps = B * args.steps / elapsed
+    recall = mean_over_ranks(np.mean(recs))
+    qps = world * B * args.steps / elapsed  # every rank completed B queries per step
     ms_per_step = elapsed / args.steps * 1e3
     log(f"{args.steps} steps: {ms_per_step:.3f} ms/step, {qps:.0f} QPS, recall@{k}={recall:.4f}")
 
@@ -385,7 +398,7 @@ def main():
 
     # ---- CPU baseline: the oracle (reference algorithm restated) on the same structures ----
     cpu = None
-    if not args.no_cpu_baseline and rank == 0:
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(fv, hyb, sharded, x, ids, is_recent, ts, now, queries[0], last if nb == 1 else run(0, nprobe, ef),
                            k, nprobe, ef, args)
 
@@ -394,15 +407,15 @@ def main():
             "metric": "k-NN queries/sec at recall@10>=0.95, 1Mx384 f32",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "c3: 1M x 384 f32 hybrid HNSW/IVF (10K-vector chunks), batch 1024, k 10",
-                       "n_vectors": N, "dim": d, "batch": B, "k": k, "recent_frac_hnsw": args.recent_frac,
+                       "n_vectors": N, "dim": d, "batch": B, "global_batch": world * B, "k": k, "recent_frac_hnsw": args.recent_frac,
                        "nlist": args.nlist, "nprobe": nprobe, "hnsw_ef": ef, "hnsw_M": 16, "hnsw_M0": 32, "hnsw_traversal": args.hnsw_traversal, "batches_in_flight": depth,
                        "other_traversal_mode": other, "hnsw_device_fallbacks": hnsw.device_fallbacks(),
                        "recall_at_10": round(recall, 4), "recall_target": args.recall_target, "sweep": sweep,
                        "generator": f"gaussian mixture: 4096 comps, means {args.spread}*N(0,I) in a rank-{args.latent} latent space, "
                                     f"unit within-comp sigma, orthonormal embedding into {d}-d + 0.02 ambient noise",
-                       "parallelism": "1 gpu" if world == 1 else f"ivf lists sharded x{world} + allgather, hnsw queries split x{world}"},
+                       "parallelism": "1 gpu" if world == 1 else f"ivf lists sharded x{world} (each rank scans its lists for all {world}x{B} queries) + all-gather of queries and of partial top-k; hnsw graph replicated, each rank searches its own {B} queries"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -1,15 +1,19 @@
 """Multi-GPU execution of the hybrid search: one process per GPU (torch.distributed, backend
-"nccl" = RCCL over xGMI on the GPU node, "gloo" in the CPU tests).
+"nccl" = RCCL over xGMI on the GPU node, "gloo" in the CPU tests and the one-GPU rehearsal).
 
-Sharding:
-  * IVF lists are owned by ranks (whole lists, largest-first greedy balance); centroids and the query
-    batch are replicated; every rank scans the probed lists it owns for ALL queries and emits a B x k
-    partial result with the selection keys (distance bits << 32 | global scan position).
-  * ONE collective per batch: all-gather of the per-rank (keys, ids) = B*k*16 bytes per rank
-    (B=1024, k=10: 160 KB) — latency-bound, so a single fused all-gather, not one per tensor.
-  * keys are unique across ranks => the G-way merge by key is exactly the single-GPU result.
-  * The HNSW graph is replicated; its queries are split over the ranks (contiguous slices) and the
-    slices' results ride in the same all-gather.
+Sharding, weak scaling — every rank brings its own batch of B queries per step:
+  * IVF lists are owned by ranks (whole lists, largest-first greedy balance); centroids are replicated.
+  * exchange 1: all-gather of the query batches (B*d*4 bytes per rank) — every rank needs every query, because
+    each scans the probed lists IT owns for ALL world*B queries and emits a partial top-k with the selection
+    keys (distance bits << 32 | global scan position).
+  * The HNSW graph is replicated: each rank searches it for its OWN B queries only (no exchange).
+  * exchange 2: all-gather of the partial (keys, ids) = world*B*k*16 bytes per rank (B=1024, k=10, 8 ranks:
+    1.3 MB) — one fused collective; each rank then keeps the world partials of its own queries.  (An all-to-all
+    would move 1/world of that; at these sizes the collective is latency-bound either way.)
+  * keys are unique across ranks => the world-way merge by key is exactly the single-GPU result; then the
+    reference's hybrid merge with the rank's HNSW results.
+Per rank the IVF work is that of a single GPU holding the whole index for B queries (1/world of the lists,
+world times the queries), so queries/s grow with the number of ranks.
 The reference has no distributed execution at all; this module is new work on top of the same
 HybridIndex surface.
 """
@@ -105,6 +109,7 @@ class ShardedHybrid:
         self.fv, self.hyb, self.rank, self.world, self.dist, self.torch = fv, hyb, rank, world, dist, torch
         self.owner = None
         self._bufs = {}
+        self._host_collectives = dist.get_backend() != "nccl"  # gloo: collectives on CPU copies (rehearsal only)
 
     def bulk_insert(self, ids, x, ts, now):
         self.owner = self.hyb.bulk_insert_sharded(ids, x, ts, now, self.rank, self.world)
@@ -112,63 +117,75 @@ class ShardedHybrid:
 
     def _tensor(self, name, shape, dtype):
         t = self._bufs.get(name)
-        if t is None or tuple(t.shape) != tuple(shape):
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
             t = self.torch.empty(shape, dtype=dtype, device="cuda")
             self._bufs[name] = t
         return t
 
-    def search_dev(self, q_dev, q_host, B, k, now, ef, nprobe):
-        torch, dist, fv = self.torch, self.dist, self.fv
-        import ctypes as C
-        ivf, hnsw, ctx = self.hyb.ivf(), self.hyb.hnsw(), self.hyb.ctx
-        keys = self._tensor("keys", (B, k), torch.int64)
-        ids = self._tensor("ids", (B, k), torch.int64)
-        ds = self._tensor("ds", (B, k), torch.float32)
-        cnt = self._tensor("cnt", (B,), torch.int32)
-        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        # 1. IVF partial for ALL queries over the lists this rank owns (async on the engine's stream)
-        ctx.check(ctx.lib.fvdb_ivf_search_dev(ivf._dev(), q_dev, B, k, nprobe, p(ids), p(ds), p(cnt), p(keys)))
-        # 2. HNSW for this rank's slice of the queries (host walk, hops scored on the GPU)
-        slices, per = query_slices(B, self.world)
-        lo, hi = slices[self.rank]
-        if hi > lo:
-            q_slice = C.c_void_p(q_dev.value + lo * self.d * 4)
-            h = hnsw.search_dev(q_slice, hi - lo, self.d, k, ef)
-            h_ids, h_ds, h_cnt = h.ids, h.distances, h.counts
+    def _all_gather(self, out, inp):
+        """out[world * n] <- concatenation over ranks of inp[n] (device tensors)."""
+        if self._host_collectives:
+            o = self.torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(o, inp.cpu())
+            out.copy_(o)
         else:
-            h_ids, h_ds, h_cnt = (np.empty((0, k), np.uint64), np.empty((0, k), np.float32), np.empty(0, np.uint32))
+            self.dist.all_gather_into_tensor(out, inp)
+
+    def upload_queries(self, q):
+        """This rank's B x d f32 query batch as a device tensor (kept by the caller across steps)."""
+        return self.torch.from_numpy(np.ascontiguousarray(q, np.float32)).cuda()
+
+    def search_dev(self, q_local, B, k, now, ef, nprobe):
+        """q_local: this rank's B x d f32 queries (device tensor).  Returns this rank's results."""
+        torch, fv, W = self.torch, self.fv, self.world
+        import ctypes as C
+        import os
+        import time
+        dbg = os.environ.get("FVDB_DEBUG_TIMING")
+        t0 = time.perf_counter()
+        ivf, hnsw, ctx = self.hyb.ivf(), self.hyb.hnsw(), self.hyb.ctx
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        d = self.d
+        # 1. every rank needs every query
+        q_all = self._tensor("q_all", (W * B, d), torch.float32)
+        self._all_gather(q_all.view(-1), q_local.reshape(-1))
+        torch.cuda.synchronize()  # the engine runs on its own streams
+        t1 = time.perf_counter()
+        # 2. IVF partial for ALL world*B queries over the lists this rank owns (async on the engine's stream)
+        keys = self._tensor("keys", (W * B, k), torch.int64)
+        ids = self._tensor("ids", (W * B, k), torch.int64)
+        ds = self._tensor("ds", (W * B, k), torch.float32)
+        cnt = self._tensor("cnt", (W * B,), torch.int32)
+        ctx.check(ctx.lib.fvdb_ivf_search_dev(ivf._dev(), p(q_all), W * B, k, nprobe, p(ids), p(ds), p(cnt), p(keys)))
+        # 3. HNSW for this rank's own queries, beside the IVF chain on the GPU
+        h = hnsw.search_dev(p(q_local), B, d, k, ef)
         ctx.synchronize()
-        # 3. one all-gather carrying IVF (keys, ids) and the HNSW slice
-        hs = np.full((per, 2 * k + 1), -1, np.int64)
-        n = h_ids.shape[0]
-        hs[:n, :k] = h_ids.view(np.int64)
-        hs[:n, k:2 * k] = h_ds.view(np.uint32).astype(np.int64)
-        hs[:n, 2 * k] = h_cnt
-        mine = self._tensor("mine", (2 * B * k + per * (2 * k + 1),), torch.int64)
-        mine[:B * k] = keys.reshape(-1)
-        mine[B * k:2 * B * k] = ids.reshape(-1)
-        mine[2 * B * k:] = torch.from_numpy(hs.reshape(-1)).cuda(non_blocking=False)
-        allb = self._tensor("all", (self.world * mine.numel(),), torch.int64)
-        dist.all_gather_into_tensor(allb, mine)
-        # 4. G-way merge by key on the GPU (fvdb_merge_keys_dev), HNSW slices back on the host
-        stride = mine.numel()
-        gk = self._tensor("gk", (self.world, B, k), torch.int64)
-        gi = self._tensor("gi", (self.world, B, k), torch.int64)
-        allv = allb.view(self.world, stride)
-        gk.copy_(allv[:, :B * k].reshape(self.world, B, k))
-        gi.copy_(allv[:, B * k:2 * B * k].reshape(self.world, B, k))
+        ctx.lib.fvdb_ivf_profile_collect(ivf._dev())  # stage timing, when profiling is on
+        t2 = time.perf_counter()
+        # 4. one collective carrying every rank's (keys, ids) for every query; keep the rows of my queries
+        mine = self._tensor("mine", (2, W * B, k), torch.int64)
+        mine[0].copy_(keys)
+        mine[1].copy_(ids)
+        allb = self._tensor("all", (W, 2, W, B, k), torch.int64)
+        self._all_gather(allb.view(-1), mine.view(-1))
+        gk = self._tensor("gk", (W, B, k), torch.int64)
+        gi = self._tensor("gi", (W, B, k), torch.int64)
+        gk.copy_(allb[:, 0, self.rank])
+        gi.copy_(allb[:, 1, self.rank])
         torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        # 5. world-way merge by key on the GPU (fvdb_merge_keys_dev), then the reference's hybrid merge
         oi = self._tensor("oi", (B, k), torch.int64)
         od = self._tensor("od", (B, k), torch.float32)
         oc = self._tensor("oc", (B,), torch.int32)
-        fv.engine.merge_keys_dev(ctx, p(gk), p(gi), self.world, B, k, p(oi), p(od), p(oc))
+        fv.engine.merge_keys_dev(ctx, p(gk), p(gi), W, B, k, p(oi), p(od), p(oc))
         ctx.synchronize()
         i_ids = oi.cpu().numpy().view(np.uint64)
         i_ds = od.cpu().numpy()
         i_cnt = oc.cpu().numpy().view(np.uint32)
-        hall = allv[:, 2 * B * k:].reshape(self.world * per, 2 * k + 1).cpu().numpy()
-        g_ids = hall[:B, :k].copy().view(np.uint64)
-        g_ds = hall[:B, k:2 * k].astype(np.uint32).view(np.float32)
-        g_cnt = np.maximum(hall[:B, 2 * k], 0).astype(np.uint32)
-        # 5. the reference's hybrid merge
-        return _Res(*hybrid_merge(g_ids, g_ds, g_cnt, i_ids, i_ds, i_cnt, k))
+        res = _Res(*hybrid_merge(h.ids, h.distances, h.counts, i_ids, i_ds, i_cnt, k))
+        if dbg and self.rank == 0:
+            t4 = time.perf_counter()
+            print(f"[sharded] gather queries {1e3*(t1-t0):.3f} ms, ivf+hnsw {1e3*(t2-t1):.3f}, gather partials {1e3*(t3-t2):.3f}, "
+                  f"merge {1e3*(t4-t3):.3f}", file=__import__("sys").stderr, flush=True)
+        return res
