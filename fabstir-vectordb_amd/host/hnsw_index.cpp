@@ -574,17 +574,9 @@ int HNSWIndex::device_launch(const float* q_dev, uint32_t B, uint32_t k, uint32_
   };
   carve(sl.d_nodes, sl.d_dist, sl.d_cnt, sl.d_status);
   carve(sl.h_nodes, sl.h_dist, sl.h_cnt, sl.h_status);
-  static const bool dbg = getenv("FVDB_DEBUG_TIMING") != nullptr;
-  const auto t0 = std::chrono::steady_clock::now();
   rc = fvdb_graph_search_dev_slot(graph_, slot == 0 ? nullptr : sl.ctx, slot, q_dev, B, k, ef, (uint32_t*)sl.d_nodes,
                                   (float*)sl.d_dist, (uint32_t*)sl.d_cnt, (uint32_t*)sl.d_status);
-  const auto t1 = std::chrono::steady_clock::now();
   if (!rc) rc = fvdb_dev_download_async(sl.ctx, sl.h_nodes, sl.d_nodes, (size_t)words * 4);
-  if (dbg) {
-    const auto t2 = std::chrono::steady_clock::now();
-    fprintf(stderr, "[hnsw slot %u] launch %.1f us, copy enqueue %.1f us\n", slot,
-            std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count());
-  }
   return rc;
 }
 

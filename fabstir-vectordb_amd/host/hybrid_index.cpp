@@ -1,7 +1,6 @@
 // hybrid_index.cpp — HybridIndex mirror (src/hybrid/core.rs): age routing, per-search
 // auto-migration, HNSW + IVF search and the stable merge.
 #include <algorithm>
-#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -278,11 +277,7 @@ int HybridIndex::search_dev_begin(uint32_t slot, const float* q_dev, uint32_t B,
   sl.recent = cfg.search_recent;
   sl.active = true;
   if (!initialized_ || B == 0 || sl.k == 0) return FVDB_OK;
-  static const bool dbg = getenv("FVDB_DEBUG_TIMING") != nullptr;
-  const auto tb0 = std::chrono::steady_clock::now();
   if (cfg_.auto_migrate) migrate_with_threshold(cfg_.recent_threshold_s, now);
-  const auto tb1 = std::chrono::steady_clock::now();
-  if (dbg) fprintf(stderr, "[hybrid begin] migrate check %.1f us\n", std::chrono::duration<double, std::micro>(tb1 - tb0).count());
   if (cfg.search_recent) {
     // the graph walk is latency-bound (one wave per query): enqueue it FIRST so that the list scan launched
     // next fills the rest of every SIMD and the two run concurrently

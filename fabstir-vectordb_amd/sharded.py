@@ -139,10 +139,7 @@ class ShardedHybrid:
         """q_local: this rank's B x d f32 queries (device tensor).  Returns this rank's results."""
         torch, fv, W = self.torch, self.fv, self.world
         import ctypes as C
-        import os
-        import time
-        dbg = os.environ.get("FVDB_DEBUG_TIMING")
-        t0 = time.perf_counter()
+
         ivf, hnsw, ctx = self.hyb.ivf(), self.hyb.hnsw(), self.hyb.ctx
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         d = self.d
@@ -150,7 +147,6 @@ class ShardedHybrid:
         q_all = self._tensor("q_all", (W * B, d), torch.float32)
         self._all_gather(q_all.view(-1), q_local.reshape(-1))
         torch.cuda.synchronize()  # the engine runs on its own streams
-        t1 = time.perf_counter()
         # 2. IVF partial for ALL world*B queries over the lists this rank owns (async on the engine's stream)
         keys = self._tensor("keys", (W * B, k), torch.int64)
         ids = self._tensor("ids", (W * B, k), torch.int64)
@@ -161,7 +157,6 @@ class ShardedHybrid:
         h = hnsw.search_dev(p(q_local), B, d, k, ef)
         ctx.synchronize()
         ctx.lib.fvdb_ivf_profile_collect(ivf._dev())  # stage timing, when profiling is on
-        t2 = time.perf_counter()
         # 4. one collective carrying every rank's (keys, ids) for every query; keep the rows of my queries
         mine = self._tensor("mine", (2, W * B, k), torch.int64)
         mine[0].copy_(keys)
@@ -173,7 +168,6 @@ class ShardedHybrid:
         gk.copy_(allb[:, 0, self.rank])
         gi.copy_(allb[:, 1, self.rank])
         torch.cuda.synchronize()
-        t3 = time.perf_counter()
         # 5. world-way merge by key on the GPU (fvdb_merge_keys_dev), then the reference's hybrid merge
         oi = self._tensor("oi", (B, k), torch.int64)
         od = self._tensor("od", (B, k), torch.float32)
@@ -183,9 +177,4 @@ class ShardedHybrid:
         i_ids = oi.cpu().numpy().view(np.uint64)
         i_ds = od.cpu().numpy()
         i_cnt = oc.cpu().numpy().view(np.uint32)
-        res = _Res(*hybrid_merge(h.ids, h.distances, h.counts, i_ids, i_ds, i_cnt, k))
-        if dbg and self.rank == 0:
-            t4 = time.perf_counter()
-            print(f"[sharded] gather queries {1e3*(t1-t0):.3f} ms, ivf+hnsw {1e3*(t2-t1):.3f}, gather partials {1e3*(t3-t2):.3f}, "
-                  f"merge {1e3*(t4-t3):.3f}", file=__import__("sys").stderr, flush=True)
-        return res
+        return _Res(*hybrid_merge(h.ids, h.distances, h.counts, i_ids, i_ds, i_cnt, k))
