@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--compare-host-walk", type=int, default=5, help="extra steps timed with the host walk (0 = skip)")
     ap.add_argument("--parts", choices=["both", "recent", "historical"], default="both",
                     help="development aid: time only the HNSW or only the IVF part of the hybrid search (recall is then meaningless)")
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="batches in flight during the timed region (1 = each step collected before the next is enqueued)")
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--spread", type=float, default=1.5)

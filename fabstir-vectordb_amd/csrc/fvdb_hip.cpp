@@ -170,7 +170,29 @@ struct Pool {
   }
 };
 
-struct fvdb_ivf {
+// Per-search scratch of an IVF index.  One set lives in the index itself; spare sets let searches on other
+// streams be in flight at the same time (fvdb_ivf_search_dev_slot swaps a spare set in for the duration of the call).
+struct IvfScratch {
+  DBuf s_qnorm, s_A;
+  DBuf s_qh, s_qn2, s_thr, s_tA, s_pa, s_surv, s_scnt, s_fail, s_mslots, s_sdist;
+  DBuf s_q, s_cpart, s_probes, s_cnt, s_fill, s_eoff, s_ioff, s_entries, s_part, s_scalars, s_ceoff, s_cioff;
+  DBuf s_in, s_slots, s_ids, s_clusters, s_out_ids, s_out_dist, s_out_cnt, s_cdist;
+  hipEvent_t sev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void release_all() {
+    DBuf* bufs[] = {&s_qnorm, &s_A, &s_qh, &s_qn2, &s_thr, &s_tA, &s_pa, &s_surv, &s_scnt, &s_fail, &s_mslots, &s_sdist,
+                    &s_q, &s_cpart, &s_probes, &s_cnt, &s_fill, &s_eoff, &s_ioff, &s_entries, &s_part, &s_scalars,
+                    &s_ceoff, &s_cioff, &s_in, &s_slots, &s_ids, &s_clusters, &s_out_ids, &s_out_dist, &s_out_cnt, &s_cdist};
+    for (DBuf* b : bufs) b->release();
+    for (auto& e : sev) {
+      if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+  }
+};
+
+struct fvdb_ivf : IvfScratch {
+  static constexpr uint32_t kSlots = 4;
+  IvfScratch spare[kSlots - 1];  // slots 1..3
   fvdb_ctx* ctx = nullptr;
   uint32_t d = 0, dpad = 0, d4 = 0, nlist = 0;
   bool trained = false;
@@ -181,11 +203,10 @@ struct fvdb_ivf {
   DBuf d_centroids_rm;   // [nlist][d]
   DBuf d_cent_pad;       // [nlist][dpad] zero padded (only when d != dpad)
   DBuf d_cnorm, d_cnmax; // |c|^2 per centroid, max |c|^2 (matrix-core coarse stage)
-  DBuf s_qnorm, s_A, s_fallbacks;
+  DBuf s_fallbacks;
   int coarse_mode = 0;   // 0 = matrix cores + exact verification when applicable, 1 = exact scan only
   int scan_mode = 0;     // same choice for the inverted-list scan
   DBuf d_xmax;           // max |x|^2 over the rows ever added (float bits)
-  DBuf s_qh, s_qn2, s_thr, s_tA, s_pa, s_surv, s_scnt, s_fail, s_mslots, s_sdist;
   Pool cpool;
   DBuf c_off, c_blocks, c_glob;  // single-list table for the centroid pool
 
@@ -201,15 +222,12 @@ struct fvdb_ivf {
   bool glob_set = false;
 
   // per-search scratch
-  DBuf s_q, s_cpart, s_probes, s_cnt, s_fill, s_eoff, s_ioff, s_entries, s_part, s_scalars, s_ceoff, s_cioff;
-  DBuf s_in, s_slots, s_ids, s_clusters, s_out_ids, s_out_dist, s_out_cnt, s_cdist;
   fvdb_search_stats last_stats{};
   // coarse scan, coarse merge, plan, fine scan, fine merge, [5] the matrix-core filter kernel alone (inside fine scan)
   float stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool pend_filter = false;
   bool pending_profile = false, pend_coarse = false, pend_fine = false, collecting = false;
   uint64_t stage_calls = 0;
-  hipEvent_t sev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 struct fvdb_store {
@@ -946,16 +964,11 @@ void fvdb_ivf_destroy(fvdb_ivf* ivf) {
   (void)hipStreamSynchronize(ivf->ctx->stream);
   ivf->pool.release();
   ivf->cpool.release();
-  DBuf* bufs[] = {&ivf->d_xmax, &ivf->s_qh, &ivf->s_qn2, &ivf->s_thr, &ivf->s_tA, &ivf->s_pa, &ivf->s_surv, &ivf->s_scnt, &ivf->s_fail, &ivf->s_mslots, &ivf->s_sdist,
-                  &ivf->d_cent_pad, &ivf->d_cnorm, &ivf->d_cnmax, &ivf->s_qnorm, &ivf->s_A, &ivf->s_fallbacks,
-                  &ivf->d_centroids_rm, &ivf->c_off, &ivf->c_blocks, &ivf->c_glob, &ivf->t_off, &ivf->t_blocks,
-                  &ivf->t_glob, &ivf->t_len, &ivf->s_q, &ivf->s_cpart, &ivf->s_probes, &ivf->s_cnt, &ivf->s_fill, &ivf->s_eoff,
-                  &ivf->s_ioff, &ivf->s_entries, &ivf->s_part, &ivf->s_scalars, &ivf->s_ceoff, &ivf->s_cioff,
-                  &ivf->s_in, &ivf->s_slots, &ivf->s_ids, &ivf->s_clusters, &ivf->s_out_ids, &ivf->s_out_dist,
-                  &ivf->s_out_cnt, &ivf->s_cdist};
+  DBuf* bufs[] = {&ivf->d_xmax, &ivf->d_cent_pad, &ivf->d_cnorm, &ivf->d_cnmax, &ivf->s_fallbacks, &ivf->d_centroids_rm,
+                  &ivf->c_off, &ivf->c_blocks, &ivf->c_glob, &ivf->t_off, &ivf->t_blocks, &ivf->t_glob, &ivf->t_len};
   for (DBuf* b : bufs) b->release();
-  for (auto& e : ivf->sev)
-    if (e) (void)hipEventDestroy(e);
+  ivf->release_all();
+  for (auto& sp : ivf->spare) sp.release_all();
   delete ivf;
 }
 
@@ -1241,6 +1254,24 @@ static int search_common(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t
 int fvdb_ivf_search_dev(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t k, uint32_t nprobe,
                         uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev, uint64_t* out_keys_dev) {
   return search_common(ivf, q_dev, B, k, nprobe, false, out_ids_dev, out_dist_dev, out_counts_dev, out_keys_dev);
+}
+
+int fvdb_ivf_search_dev_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t k,
+                             uint32_t nprobe, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev,
+                             uint64_t* out_keys_dev) {
+  if (slot >= fvdb_ivf::kSlots) FAIL(ivf->ctx, FVDB_E_INVALID, "slot out of range");
+  if (on && on->device != ivf->ctx->device) FAIL(ivf->ctx, FVDB_E_INVALID, "context of another device");
+  // the slot's scratch set and stream stand in for the index's own for the duration of the call: every launch
+  // below goes to `on`'s stream and touches only this slot's scratch, so slots can be in flight together
+  IvfScratch& mine = *ivf;
+  fvdb_ctx* home = ivf->ctx;
+  if (slot > 0) std::swap(mine, ivf->spare[slot - 1]);
+  if (on) ivf->ctx = on;
+  const int rc = search_common(ivf, q_dev, B, k, nprobe, false, out_ids_dev, out_dist_dev, out_counts_dev, out_keys_dev);
+  if (rc && on) home->err = on->err;
+  ivf->ctx = home;
+  if (slot > 0) std::swap(mine, ivf->spare[slot - 1]);
+  return rc;
 }
 
 int fvdb_ivf_search_all_dev(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t k, uint64_t* out_ids_dev,

@@ -90,8 +90,9 @@ class IVFIndex {
   int search(const float* q, uint32_t B, uint32_t dim, uint32_t k, uint32_t n_probe, uint64_t* ids, float* dist,
              uint32_t* counts);                                                   // :626, operations.rs:132
   // same with the queries already resident in HBM (B x d row-major); outputs are device pointers
+  // `on` / `slot`: run on another context's stream with that slot's scratch set (several searches in flight)
   int search_dev(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t n_probe, uint64_t* ids_dev,
-                 float* dist_dev, uint32_t* counts_dev);
+                 float* dist_dev, uint32_t* counts_dev, fvdb_ctx* on = nullptr, uint32_t slot = 0);
   int mark_deleted(uint64_t id);                                                  // operations.rs:569
   bool is_deleted(uint64_t id) const { return deleted_.count(id) > 0; }
   uint64_t active_count() const { return total_ - deleted_.size(); }
@@ -341,6 +342,7 @@ class HybridIndex {
     void *h_hid = nullptr, *h_hd = nullptr, *h_hc = nullptr;  // pinned host copies
     uint64_t cap = 0;
     fvdb_event* ivf_done = nullptr;
+    fvdb_ctx* ivf_ctx = nullptr;  // slot 0 borrows ctx_ivf_, the others own a context (stream) each
     bool active = false, ivf_in_flight = false, hnsw_in_flight = false, recent = false;
     const float* q = nullptr;
     uint32_t B = 0, dim = 0, k = 0, rk = 0, hk = 0, ef = 0;

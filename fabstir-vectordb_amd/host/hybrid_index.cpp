@@ -19,6 +19,7 @@ HybridIndex::~HybridIndex() {
     if (sl.d_hid) fvdb_dev_free(ctx_ivf_, sl.d_hid);  // the other pointers are carved out of these two blocks
     if (sl.h_hid) fvdb_host_free(ctx_ivf_, sl.h_hid);
     if (sl.ivf_done) fvdb_event_destroy(sl.ivf_done);
+    if (sl.ivf_ctx && sl.ivf_ctx != ctx_ivf_) fvdb_ctx_destroy(sl.ivf_ctx);
   }
   delete recent_;
   delete historical_;
@@ -266,7 +267,7 @@ int HybridIndex::search_dev_begin(uint32_t slot, const float* q_dev, uint32_t B,
   if (slot >= kSlots) return FVDB_E_INVALID;
   Slot& sl = slots_[slot];
   if (sl.active) return FVDB_E_INVALID;  // the previous batch of this slot was never collected
-  sl = Slot{sl.d_hid, sl.d_hd, sl.d_hc, sl.h_hid, sl.h_hd, sl.h_hc, sl.cap, sl.ivf_done};
+  sl = Slot{sl.d_hid, sl.d_hd, sl.d_hc, sl.h_hid, sl.h_hd, sl.h_hc, sl.cap, sl.ivf_done, sl.ivf_ctx};
   sl.q = q_dev;
   sl.B = B;
   sl.dim = dim;
@@ -300,12 +301,20 @@ int HybridIndex::search_dev_begin(uint32_t slot, const float* q_dev, uint32_t B,
     sl.d_hc = (char*)sl.d_hid + need * 12;
     sl.h_hd = (char*)sl.h_hid + need * 8;
     sl.h_hc = (char*)sl.h_hid + need * 12;
-    if (!sl.ivf_done && fvdb_event_create(ctx_ivf_, &sl.ivf_done)) return FVDB_E_HIP;
+    // each slot's IVF chain runs on its own stream with its own scratch set, so the chains of consecutive batches
+    // overlap (a chain is ~20 dependent launches with gaps between them)
+    static const bool one_stream = getenv("FVDB_IVF_ONE_STREAM") != nullptr;  // tuning aid
+    if (!sl.ivf_ctx) {
+      if (slot == 0 || one_stream) sl.ivf_ctx = ctx_ivf_;
+      else if (fvdb_ctx_create(fvdb_ctx_device(ctx_ivf_), &sl.ivf_ctx)) return FVDB_E_HIP;
+    }
+    fvdb_ctx* on = sl.ivf_ctx == ctx_ivf_ ? nullptr : sl.ivf_ctx;
+    if (!sl.ivf_done && fvdb_event_create(sl.ivf_ctx, &sl.ivf_done)) return FVDB_E_HIP;
     sl.ivf_in_flight = historical_->search_dev(q_dev, B, dim, sl.hk, (uint32_t)cfg.ivf_n_probe, (uint64_t*)sl.d_hid,
-                                               (float*)sl.d_hd, (uint32_t*)sl.d_hc) == FVDB_OK;
+                                               (float*)sl.d_hd, (uint32_t*)sl.d_hc, on, on ? slot : 0) == FVDB_OK;
     if (sl.ivf_in_flight) {
-      // result copies ride the IVF stream right behind the chain (before the next batch's chain), then the event
-      if (fvdb_dev_download_async(ctx_ivf_, sl.h_hid, sl.d_hid, (size_t)bytes) || fvdb_event_record(ctx_ivf_, sl.ivf_done))
+      // result copy rides the slot's stream right behind the chain, then the event
+      if (fvdb_dev_download_async(sl.ivf_ctx, sl.h_hid, sl.d_hid, (size_t)bytes) || fvdb_event_record(sl.ivf_ctx, sl.ivf_done))
         return FVDB_E_HIP;
     }
   }
@@ -336,7 +345,7 @@ int HybridIndex::search_dev_end(uint32_t slot, uint64_t* ids, float* dist, uint3
     have_r = rc2 == FVDB_OK;
   }
   if (sl.ivf_in_flight) {
-    have_h = fvdb_event_wait(ctx_ivf_, sl.ivf_done) == FVDB_OK;
+    have_h = fvdb_event_wait(sl.ivf_ctx, sl.ivf_done) == FVDB_OK;
     bool busy = false;
     for (const Slot& o : slots_) busy = busy || o.active;
     if (!busy) fvdb_ivf_profile_collect(historical_->device());  // stage timing only makes sense one batch at a time

@@ -172,10 +172,10 @@ int IVFIndex::search(const float* q, uint32_t B, uint32_t dim, uint32_t k, uint3
 }
 
 int IVFIndex::search_dev(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t n_probe, uint64_t* ids_dev,
-                         float* dist_dev, uint32_t* counts_dev) {
+                         float* dist_dev, uint32_t* counts_dev, fvdb_ctx* on, uint32_t slot) {
   if (!trained_) return FVDB_E_NOT_TRAINED;
   if (dim != dim_) return FVDB_E_DIM;
-  return fvdb_ivf_search_dev(dev_, q_dev, B, k, n_probe, ids_dev, dist_dev, counts_dev, nullptr);
+  return fvdb_ivf_search_dev_slot(dev_, on, slot, q_dev, B, k, n_probe, ids_dev, dist_dev, counts_dev, nullptr);
 }
 
 // src/ivf/operations.rs:569-591

@@ -159,6 +159,12 @@ int fvdb_ivf_search_dev(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t 
  * with no coarse step). */
 int fvdb_ivf_search_all(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t k, uint64_t* out_ids,
                         float* out_dist, uint32_t* out_counts);
+/* Same search on the stream of context `on` (NULL = the index's own) with the slot-th (0..3) set of per-search
+ * scratch: searches in different slots and on different contexts may be in flight together.  The index must not be
+ * modified while any is.  Stage timing (profiling) is only kept for searches on the index's own context. */
+int fvdb_ivf_search_dev_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t k,
+                             uint32_t nprobe, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev,
+                             uint64_t* out_keys_dev);
 int fvdb_ivf_search_all_dev(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t k, uint64_t* out_ids_dev,
                             float* out_dist_dev, uint32_t* out_counts_dev);
 /* Coarse step alone (src/ivf/core.rs:645-656): the nprobe nearest clusters per query in
