@@ -5,6 +5,7 @@ O=gpurun_out/final
 rm -rf $O && mkdir -p $O
 echo "== default bench"; python3 bench.py > $O/bench_c3_default.json 2> $O/bench_c3_default.log; tail -n 3 $O/bench_c3_default.log
 echo "== one batch at a time"; python3 bench.py --no-cpu-baseline --compare-host-walk 0 --in-flight 1 > $O/bench_c3_in_flight_1.json 2> $O/bench_c3_in_flight_1.log; tail -n 1 $O/bench_c3_in_flight_1.log
+echo "== tiny run (2 steps, no warmup)"; python3 bench.py --no-cpu-baseline --compare-host-walk 0 --nprobe 32 --ef 50 --steps 2 --warmup 0 2>&1 | tail -n 2 | cut -c1-120
 echo "== sharded path forced on one rank"; FVDB_FORCE_SHARDED=1 python3 bench.py --steps 10 --compare-host-walk 0 --cpu-sample 256 > $O/bench_c3_forced_sharded.json 2> $O/bench_c3_forced_sharded.log; tail -n 2 $O/bench_c3_forced_sharded.log
 echo "== rocprofv3 kernel trace of the bench command"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python3 bench.py --no-cpu-baseline --compare-host-walk 0 > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.log
