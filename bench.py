@@ -264,7 +264,8 @@ def main():
 
     ctx_ivf.set_profiling(2)      # on before the warm-up: the first profiled search creates events etc.
     ctx_hnsw.set_profiling(2)     # HIP events around the traversal kernel (its own stream)
-    for i in range(args.warmup):
+    # the multi-GPU path has more lazily initialised parts (RCCL channels, torch's staging buffers): extra warm-up
+    for i in range(args.warmup if sharded is None else max(args.warmup, 12)):
         run(i, nprobe, ef)
     if depth > 1:
         pipelined(max(args.warmup, 2 * depth))  # every slot has its stream, buffers and traversal state before timing

@@ -139,6 +139,12 @@ class ShardedHybrid:
         """q_local: this rank's B x d f32 queries (device tensor).  Returns this rank's results."""
         torch, fv, W = self.torch, self.fv, self.world
         import ctypes as C
+        import os
+        import sys
+        import time
+        timing = os.environ.get("FVDB_SHARDED_TIMING")  # diagnostic: per-phase host time of every call, rank 0
+        tp = [time.perf_counter()]
+        mark = (lambda: tp.append(time.perf_counter())) if timing else (lambda: None)
 
         ivf, hnsw, ctx = self.hyb.ivf(), self.hyb.hnsw(), self.hyb.ctx
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
@@ -147,6 +153,7 @@ class ShardedHybrid:
         q_all = self._tensor("q_all", (W * B, d), torch.float32)
         self._all_gather(q_all.view(-1), q_local.reshape(-1))
         torch.cuda.synchronize()  # the engine runs on its own streams
+        mark()
         # 2. IVF partial for ALL world*B queries over the lists this rank owns (async on the engine's stream)
         keys = self._tensor("keys", (W * B, k), torch.int64)
         ids = self._tensor("ids", (W * B, k), torch.int64)
@@ -157,6 +164,7 @@ class ShardedHybrid:
         h = hnsw.search_dev(p(q_local), B, d, k, ef)
         ctx.synchronize()
         ctx.lib.fvdb_ivf_profile_collect(ivf._dev())  # stage timing, when profiling is on
+        mark()
         # 4. one collective carrying every rank's (keys, ids) for every query; keep the rows of my queries
         mine = self._tensor("mine", (2, W * B, k), torch.int64)
         mine[0].copy_(keys)
@@ -168,13 +176,22 @@ class ShardedHybrid:
         gk.copy_(allb[:, 0, self.rank])
         gi.copy_(allb[:, 1, self.rank])
         torch.cuda.synchronize()
+        mark()
         # 5. world-way merge by key on the GPU (fvdb_merge_keys_dev), then the reference's hybrid merge
         oi = self._tensor("oi", (B, k), torch.int64)
         od = self._tensor("od", (B, k), torch.float32)
         oc = self._tensor("oc", (B,), torch.int32)
         fv.engine.merge_keys_dev(ctx, p(gk), p(gi), W, B, k, p(oi), p(od), p(oc))
         ctx.synchronize()
+        mark()
         i_ids = oi.cpu().numpy().view(np.uint64)
         i_ds = od.cpu().numpy()
         i_cnt = oc.cpu().numpy().view(np.uint32)
-        return _Res(*hybrid_merge(h.ids, h.distances, h.counts, i_ids, i_ds, i_cnt, k))
+        mark()
+        res = _Res(*hybrid_merge(h.ids, h.distances, h.counts, i_ids, i_ds, i_cnt, k))
+        if timing and self.rank == 0:
+            mark()
+            names = ("gather queries", "ivf+hnsw", "gather partials", "merge kernel", "copies to host", "hybrid merge")
+            print("[sharded] " + ", ".join(f"{n} {1e3 * (b - a):.3f}" for n, a, b in zip(names, tp, tp[1:])) + " ms",
+                  file=sys.stderr, flush=True)
+        return res
