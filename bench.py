@@ -273,6 +273,15 @@ def main():
     hyb.ivf_device_stage_times()  # reset accumulators
     hnsw = hyb.hnsw()
     hnsw.graph_kernel_times()
+    if dist is not None:
+        # a barrier is followed, a few searches later, by a one-off stall of tens of ms (seen with RCCL on one rank
+        # as well): take it outside the timed region — barrier, a few untimed searches, barrier again
+        dist.barrier()
+        torch.cuda.synchronize()
+        for i in range(6):
+            run(i, nprobe, ef)
+        hyb.ivf_device_stage_times()
+        hnsw.graph_kernel_times()
     evals0, hops0 = hnsw.dist_evals(), hnsw.hops()
     if dist is not None:
         dist.barrier()
@@ -289,13 +298,15 @@ def main():
         # previous batch's on the IVF stream) before step i - depth + 1 is collected and merged on the host.  Every
         # step's results are complete, on the host, inside the timed region.
         last, t_begin, t_end = pipelined(args.steps)
+    t_loop = time.perf_counter() - t0
     ctx_ivf.synchronize()
     ctx_hnsw.synchronize()
     if dist is not None:
         torch.cuda.synchronize()
+        t_sync = time.perf_counter() - t0
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    log(f"timed region done: {elapsed:.3f}s")
+    log(f"timed region done: {elapsed:.3f}s" + (f" (loop {t_loop:.4f}s, synced {t_sync:.4f}s)" if dist is not None else ""))
     if depth > 1:
         log(f"host time per step: enqueue {t_begin / args.steps * 1e3:.3f} ms, collect+merge (incl. waiting) {t_end / args.steps * 1e3:.3f} ms")
     if dist is not None:

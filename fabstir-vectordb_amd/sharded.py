@@ -192,6 +192,6 @@ class ShardedHybrid:
         if timing and self.rank == 0:
             mark()
             names = ("gather queries", "ivf+hnsw", "gather partials", "merge kernel", "copies to host", "hybrid merge")
-            print("[sharded] " + ", ".join(f"{n} {1e3 * (b - a):.3f}" for n, a, b in zip(names, tp, tp[1:])) + " ms",
+            print(f"[sharded] t_in {tp[0] % 10:.6f} t_out {tp[-1] % 10:.6f} " + ", ".join(f"{n} {1e3 * (b - a):.3f}" for n, a, b in zip(names, tp, tp[1:])) + " ms",
                   file=sys.stderr, flush=True)
         return res
