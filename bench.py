@@ -239,9 +239,16 @@ def main():
     log(f"operating point: nprobe={nprobe} ef={ef}")
 
     # ---- timed region ----
-    depth = max(1, min(args.in_flight, 4)) if sharded is None else 1
+    depth = max(1, min(args.in_flight, 4))
     kw = dict(now=now, hnsw_ef=ef, ivf_n_probe=nprobe, dim=d, search_recent=args.parts != "historical",
               search_historical=args.parts != "recent")
+
+    if sharded is None:
+        begin = lambda slot, i: hyb.search_dev_begin(slot, qdev[i % nb], B, k, **kw)  # noqa: E731
+        end = hyb.search_dev_end
+    else:  # every rank runs the same sequence of begin/end calls (each holds one collective)
+        begin = lambda slot, i: sharded.search_dev_begin(slot, qdev[i % nb], B, k, now, ef, nprobe)  # noqa: E731
+        end = sharded.search_dev_end
 
     def pipelined(nsteps):
         """nsteps searches with up to `depth` batches in flight; returns the last result and the host time spent
@@ -250,15 +257,15 @@ def main():
         res = None
         for i in range(nsteps):
             ta = time.perf_counter()
-            hyb.search_dev_begin(i % depth, qdev[i % nb], B, k, **kw)  # slot i % depth was collected one iteration ago
+            begin(i % depth, i)  # slot i % depth was collected one iteration ago
             tb = time.perf_counter()
             if i >= depth - 1:
-                res = hyb.search_dev_end((i - depth + 1) % depth)
+                res = end((i - depth + 1) % depth)
             t_begin += tb - ta
             t_end += time.perf_counter() - tb
         for i in range(max(nsteps - depth + 1, 0), nsteps):
             ta = time.perf_counter()
-            res = hyb.search_dev_end(i % depth)
+            res = end(i % depth)
             t_end += time.perf_counter() - ta
         return res, t_begin, t_end
 

@@ -198,6 +198,18 @@ int fvh_hybrid_search_dev_begin(void* p, uint32_t slot, const float* q_dev, uint
 int fvh_hybrid_search_dev_end(void* p, uint32_t slot, uint64_t* ids, float* dist, uint32_t* counts) {
   return ((HybridIndex*)p)->search_dev_end(slot, ids, dist, counts);
 }
+// device traversal split in two (several batches in flight): begin returns 1 when the launch is in flight in `slot`,
+// 0 when this search cannot run on the device path (call fvh_hnsw_search_dev instead of _end), < 0 on error
+int fvh_hnsw_search_dev_begin(void* p, uint32_t slot, const float* q_dev, uint32_t B, uint32_t d, uint32_t k, uint32_t ef) {
+  int rc = 0;
+  const bool started = ((HNSWIndex*)p)->search_dev_begin(q_dev, B, d, k, ef, &rc, slot);
+  if (rc) return rc < 0 ? rc : -rc;
+  return started ? 1 : 0;
+}
+int fvh_hnsw_search_dev_end(void* p, uint32_t slot, const float* q_dev, uint32_t B, uint32_t d, uint32_t k, uint32_t ef,
+                            uint64_t* ids, float* dist, uint32_t* counts) {
+  return ((HNSWIndex*)p)->search_dev_end(q_dev, B, d, k, ef, ids, dist, counts, slot);
+}
 int fvh_hnsw_search_dev(void* p, const float* q_dev, uint32_t B, uint32_t d, uint32_t k, uint32_t ef, uint64_t* ids,
                         float* dist, uint32_t* counts) {
   return ((HNSWIndex*)p)->search_dev(q_dev, B, d, k, ef, ids, dist, counts);

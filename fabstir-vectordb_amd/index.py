@@ -79,6 +79,8 @@ HOST_SIGNATURES = {
     "fvh_hybrid_search_dev_begin": (i32, [vp, u32, vp, u32, u32, u64, u64, u64, i32, i32, u64, u64, dbl]),
     "fvh_hybrid_search_dev_end": (i32, [vp, u32, u64p, f32p, u32p]),
     "fvh_hnsw_search_dev": (i32, [vp, vp, u32, u32, u32, u32, u64p, f32p, u32p]),
+    "fvh_hnsw_search_dev_begin": (i32, [vp, u32, vp, u32, u32, u32, u32]),
+    "fvh_hnsw_search_dev_end": (i32, [vp, u32, vp, u32, u32, u32, u32, u64p, f32p, u32p]),
     "fvh_hybrid_delete": (i32, [vp, u64, dbl]),
     "fvh_hybrid_migrate": (u64, [vp, dbl, dbl]),
     "fvh_hybrid_recent_count": (u64, [vp]),
@@ -310,6 +312,26 @@ class HNSWIndex(_Base):
         cnt = np.zeros(B, np.uint32)
         self._check(self.lib.fvh_hnsw_search_dev(self.h, q_dev, B, dim, k, ef, _ptr(ids, u64p), _ptr(ds, f32p),
                                                  _ptr(cnt, u32p)))
+        return SearchResults(ids, ds, cnt)
+
+    def search_dev_begin(self, slot, q_dev, B, dim, k, ef):
+        """Enqueue the device traversal of a batch in `slot` (0..3); the query buffer must stay valid until
+        search_dev_end(slot)."""
+        rc = self.lib.fvh_hnsw_search_dev_begin(self.h, slot, q_dev, B, dim, k, ef)
+        if rc < 0:
+            self._check(-rc)
+        self._inflight = getattr(self, "_inflight", {})
+        self._inflight[slot] = (q_dev, B, dim, k, ef, rc == 1)
+
+    def search_dev_end(self, slot):
+        q_dev, B, dim, k, ef, started = self._inflight.pop(slot)
+        if not started:  # not a device-path search (host-walk mode, empty index ...): run it now
+            return self.search_dev(q_dev, B, dim, k, ef)
+        ids = np.empty((B, max(k, 1)), np.uint64)
+        ds = np.empty((B, max(k, 1)), np.float32)
+        cnt = np.zeros(B, np.uint32)
+        self._check(self.lib.fvh_hnsw_search_dev_end(self.h, slot, q_dev, B, dim, k, ef, _ptr(ids, u64p), _ptr(ds, f32p),
+                                                     _ptr(cnt, u32p)))
         return SearchResults(ids, ds, cnt)
 
     def node_count(self):

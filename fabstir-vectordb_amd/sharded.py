@@ -110,6 +110,7 @@ class ShardedHybrid:
         self.owner = None
         self._bufs = {}
         self._host_collectives = dist.get_backend() != "nccl"  # gloo: collectives on CPU copies (rehearsal only)
+        self._hnsw = hyb.hnsw()  # one wrapper object: it remembers the searches in flight per slot
 
     def bulk_insert(self, ids, x, ts, now):
         self.owner = self.hyb.bulk_insert_sharded(ids, x, ts, now, self.rank, self.world)
@@ -134,6 +135,72 @@ class ShardedHybrid:
     def upload_queries(self, q):
         """This rank's B x d f32 query batch as a device tensor (kept by the caller across steps)."""
         return self.torch.from_numpy(np.ascontiguousarray(q, np.float32)).cuda()
+
+    SLOTS = 4
+
+    def _slot_ctx(self, slot):
+        """Engine context (stream) of the slot's IVF chain: slot 0 = the index's own."""
+        if slot == 0:
+            return self.hyb.ctx
+        c = self._bufs.get(("ctx", slot))
+        if c is None:
+            c = self.fv.Context(self.hyb.ctx.device)
+            self._bufs[("ctx", slot)] = c
+        return c
+
+    def search_dev_begin(self, slot, q_local, B, k, now, ef, nprobe):
+        """Enqueue this rank's step in `slot`: gather everyone's queries, start the IVF chain over the lists this rank
+        owns (slot's stream and scratch) and the graph walk of its own queries.  Every rank must call begin/end in the
+        same order (each contains one collective)."""
+        torch, W, d = self.torch, self.world, self.d
+        import ctypes as C
+        ivf, hnsw, ctx = self.hyb.ivf(), self._hnsw, self.hyb.ctx
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        sc = self._slot_ctx(slot)
+        q_all = self._tensor(("q_all", slot), (W * B, d), torch.float32)
+        self._all_gather(q_all.view(-1), q_local.reshape(-1))
+        torch.cuda.current_stream().synchronize()  # the engine runs on its own streams; other slots keep running
+        keys = self._tensor(("keys", slot), (W * B, k), torch.int64)
+        ids = self._tensor(("ids", slot), (W * B, k), torch.int64)
+        ds = self._tensor(("ds", slot), (W * B, k), torch.float32)
+        cnt = self._tensor(("cnt", slot), (W * B,), torch.int32)
+        ctx.check(ctx.lib.fvdb_ivf_search_dev_slot(ivf._dev(), None if slot == 0 else sc.h, slot, p(q_all), W * B, k, nprobe,
+                                                   p(ids), p(ds), p(cnt), p(keys)))
+        hnsw.search_dev_begin(slot, p(q_local), B, d, k, ef)
+        self._bufs[("state", slot)] = (q_local, B, k)
+
+    def search_dev_end(self, slot):
+        """Collect the step of `slot`: wait for its walk and chain, exchange the partial top-k, merge."""
+        torch, fv, W = self.torch, self.fv, self.world
+        import ctypes as C
+        q_local, B, k = self._bufs.pop(("state", slot))
+        ivf, hnsw, ctx = self.hyb.ivf(), self._hnsw, self.hyb.ctx
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        h = hnsw.search_dev_end(slot)
+        self._slot_ctx(slot).synchronize()
+        if slot == 0:
+            ctx.lib.fvdb_ivf_profile_collect(ivf._dev())  # stage timing, when profiling is on
+        keys, ids = self._bufs[("keys", slot)], self._bufs[("ids", slot)]
+        mine = self._tensor(("mine", slot), (2, W * B, k), torch.int64)
+        mine[0].copy_(keys)
+        mine[1].copy_(ids)
+        allb = self._tensor(("all", slot), (W, 2, W, B, k), torch.int64)
+        self._all_gather(allb.view(-1), mine.view(-1))
+        gk = self._tensor(("gk", slot), (W, B, k), torch.int64)
+        gi = self._tensor(("gi", slot), (W, B, k), torch.int64)
+        gk.copy_(allb[:, 0, self.rank])
+        gi.copy_(allb[:, 1, self.rank])
+        torch.cuda.current_stream().synchronize()
+        oi = self._tensor(("oi", slot), (B, k), torch.int64)
+        od = self._tensor(("od", slot), (B, k), torch.float32)
+        oc = self._tensor(("oc", slot), (B,), torch.int32)
+        sc = self._slot_ctx(slot)
+        fv.engine.merge_keys_dev(sc, p(gk), p(gi), W, B, k, p(oi), p(od), p(oc))
+        sc.synchronize()
+        i_ids = oi.cpu().numpy().view(np.uint64)
+        i_ds = od.cpu().numpy()
+        i_cnt = oc.cpu().numpy().view(np.uint32)
+        return _Res(*hybrid_merge(h.ids, h.distances, h.counts, i_ids, i_ds, i_cnt, k))
 
     def search_dev(self, q_local, B, k, now, ef, nprobe):
         """q_local: this rank's B x d f32 queries (device tensor).  Returns this rank's results."""
