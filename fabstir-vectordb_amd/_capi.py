@@ -90,6 +90,8 @@ SIGNATURES = {
     "fvdb_graph_search_dev_slot": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp, vp, vp]),
     "fvdb_ctx_device": (i32, [vp]),
     "fvdb_ivf_search_dev_slot": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp, vp, vp]),
+    "fvdb_ivf_coarse_dev_slot": (i32, [vp, vp, u32, vp, u32, u32, vp]),
+    "fvdb_ivf_search_probes_dev_slot": (i32, [vp, vp, u32, vp, vp, u32, u32, u32, vp, vp, vp, vp]),
     "fvdb_host_alloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
     "fvdb_host_free": (None, [vp, vp]),
     "fvdb_dev_download_async": (i32, [vp, vp, vp, C.c_size_t]),

@@ -1214,8 +1214,11 @@ int fvdb_ivf_set_deleted(fvdb_ivf* ivf, const uint32_t* cluster, const uint32_t*
   return FVDB_OK;
 }
 
+// given_probes (device, [B][min(nprobe, nlist)] cluster ids in probe order): the coarse stage is skipped.
+// probes_only (device, same shape): only the coarse stage runs and its result is copied there.
 static int search_common(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t k, uint32_t nprobe, bool all,
-                         uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys) {
+                         uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys,
+                         const uint32_t* given_probes = nullptr, uint32_t* probes_only = nullptr) {
   fvdb_ctx* ctx = ivf->ctx;
   if (!ivf->trained) FAIL(ctx, FVDB_E_NOT_TRAINED, "index not trained");
   if (k == 0 || k > FVDB_MAX_K) FAIL(ctx, FVDB_E_UNSUPPORTED, "k must be in 1..FVDB_MAX_K");
@@ -1233,15 +1236,24 @@ static int search_common(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t
     rc = padded_queries(ivf, q_dev + (size_t)o * ivf->d, b, &qpad);
     if (rc) return rc;
     HIPCHK(ctx, ivf->s_probes.ensure((size_t)b * np * 4));
+    const uint32_t* probes = ivf->s_probes.as<uint32_t>();
     if (all) {
       hipLaunchKernelGGL(probes_all_kernel, dim3(cdiv((uint64_t)b * np, 256)), dim3(256), 0, ctx->stream, b, np,
                          ivf->s_probes.as<uint32_t>());
       if (ctx->profiling) (void)hipEventRecord(ivf->sev[2], ctx->stream);
+    } else if (given_probes) {
+      probes = given_probes + (size_t)o * np;
+      if (ctx->profiling) {  // no coarse stage in this call: zero-length stage intervals
+        (void)hipEventRecord(ivf->sev[0], ctx->stream);
+        (void)hipEventRecord(ivf->sev[1], ctx->stream);
+        (void)hipEventRecord(ivf->sev[2], ctx->stream);
+      }
     } else {
-      rc = run_coarse(ivf, qpad, b, np, ivf->s_probes.as<uint32_t>(), nullptr);
+      rc = run_coarse(ivf, qpad, b, np, probes_only ? probes_only + (size_t)o * np : ivf->s_probes.as<uint32_t>(), nullptr);
       if (rc) return rc;
     }
-    rc = run_fine(ivf, qpad, b, k, np, ivf->s_probes.as<uint32_t>(), out_ids ? out_ids + (size_t)o * k : nullptr,
+    if (probes_only) continue;
+    rc = run_fine(ivf, qpad, b, k, np, probes, out_ids ? out_ids + (size_t)o * k : nullptr,
                   out_dist ? out_dist + (size_t)o * k : nullptr, out_counts ? out_counts + o : nullptr,
                   out_keys ? out_keys + (size_t)o * k : nullptr, all ? ROLE_ALL : ROLE_LIST);
     if (rc) return rc;
@@ -1256,22 +1268,50 @@ int fvdb_ivf_search_dev(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t 
   return search_common(ivf, q_dev, B, k, nprobe, false, out_ids_dev, out_dist_dev, out_counts_dev, out_keys_dev);
 }
 
-int fvdb_ivf_search_dev_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t k,
-                             uint32_t nprobe, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev,
-                             uint64_t* out_keys_dev) {
+// shared by the slot entry points: run `body` with the slot's scratch set and `on`'s stream standing in
+extern "C++" {
+template <typename F>
+static int with_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, F body) {
   if (slot >= fvdb_ivf::kSlots) FAIL(ivf->ctx, FVDB_E_INVALID, "slot out of range");
   if (on && on->device != ivf->ctx->device) FAIL(ivf->ctx, FVDB_E_INVALID, "context of another device");
-  // the slot's scratch set and stream stand in for the index's own for the duration of the call: every launch
-  // below goes to `on`'s stream and touches only this slot's scratch, so slots can be in flight together
   IvfScratch& mine = *ivf;
   fvdb_ctx* home = ivf->ctx;
   if (slot > 0) std::swap(mine, ivf->spare[slot - 1]);
   if (on) ivf->ctx = on;
-  const int rc = search_common(ivf, q_dev, B, k, nprobe, false, out_ids_dev, out_dist_dev, out_counts_dev, out_keys_dev);
+  const int rc = body();
   if (rc && on) home->err = on->err;
   ivf->ctx = home;
   if (slot > 0) std::swap(mine, ivf->spare[slot - 1]);
   return rc;
+}
+}  // extern "C++"
+
+int fvdb_ivf_coarse_dev_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t nprobe,
+                             uint32_t* out_probes_dev) {
+  if (!out_probes_dev) FAIL(ivf->ctx, FVDB_E_INVALID, "null output");
+  return with_slot(ivf, on, slot, [&]() {
+    return search_common(ivf, q_dev, B, 1, nprobe, false, nullptr, nullptr, nullptr, nullptr, nullptr, out_probes_dev);
+  });
+}
+
+int fvdb_ivf_search_probes_dev_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev,
+                                    const uint32_t* probes_dev, uint32_t B, uint32_t k, uint32_t nprobe,
+                                    uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev,
+                                    uint64_t* out_keys_dev) {
+  if (!probes_dev) FAIL(ivf->ctx, FVDB_E_INVALID, "null probes");
+  return with_slot(ivf, on, slot, [&]() {
+    return search_common(ivf, q_dev, B, k, nprobe, false, out_ids_dev, out_dist_dev, out_counts_dev, out_keys_dev, probes_dev);
+  });
+}
+
+int fvdb_ivf_search_dev_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t k,
+                             uint32_t nprobe, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev,
+                             uint64_t* out_keys_dev) {
+  // the slot's scratch set and stream stand in for the index's own for the duration of the call: every launch
+  // goes to `on`'s stream and touches only this slot's scratch, so slots can be in flight together
+  return with_slot(ivf, on, slot, [&]() {
+    return search_common(ivf, q_dev, B, k, nprobe, false, out_ids_dev, out_dist_dev, out_counts_dev, out_keys_dev);
+  });
 }
 
 int fvdb_ivf_search_all_dev(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t k, uint64_t* out_ids_dev,

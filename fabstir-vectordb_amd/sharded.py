@@ -3,9 +3,10 @@
 
 Sharding, weak scaling — every rank brings its own batch of B queries per step:
   * IVF lists are owned by ranks (whole lists, largest-first greedy balance); centroids are replicated.
-  * exchange 1: all-gather of the query batches (B*d*4 bytes per rank) — every rank needs every query, because
-    each scans the probed lists IT owns for ALL world*B queries and emits a partial top-k with the selection
-    keys (distance bits << 32 | global scan position).
+  * each rank ranks the centroids for its OWN queries; exchange 1: all-gather of the query batches with their
+    probe lists (B*(d+nprobe)*4 bytes per rank) — every rank needs every query, because each scans the probed
+    lists IT owns for ALL world*B queries and emits a partial top-k with the selection keys (distance bits << 32 |
+    global scan position).
   * The HNSW graph is replicated: each rank searches it for its OWN B queries only (no exchange).
   * exchange 2: all-gather of the partial (keys, ids) = world*B*k*16 bytes per rank (B=1024, k=10, 8 ranks:
     1.3 MB) — one fused collective; each rank then keeps the world partials of its own queries.  (An all-to-all
@@ -157,15 +158,29 @@ class ShardedHybrid:
         ivf, hnsw, ctx = self.hyb.ivf(), self._hnsw, self.hyb.ctx
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         sc = self._slot_ctx(slot)
+        on = None if slot == 0 else sc.h
+        npb = min(nprobe, self.hyb.n_clusters)
+        # coarse stage for this rank's own queries only; the probe lists travel with the queries in ONE collective
+        probes = self._tensor(("probes", slot), (B, npb), torch.int32)
+        ctx.check(ctx.lib.fvdb_ivf_coarse_dev_slot(ivf._dev(), on, slot, p(q_local), B, nprobe, p(probes)))
+        sc.synchronize()
+        pack = self._tensor(("pack", slot), (B, d + npb), torch.int32)
+        pack[:, :d].copy_(q_local.view(torch.int32))
+        pack[:, d:].copy_(probes)
+        pack_all = self._tensor(("pack_all", slot), (W * B, d + npb), torch.int32)
+        self._all_gather(pack_all.view(-1), pack.view(-1))
         q_all = self._tensor(("q_all", slot), (W * B, d), torch.float32)
-        self._all_gather(q_all.view(-1), q_local.reshape(-1))
+        q_all.view(torch.int32).copy_(pack_all[:, :d])
+        probes_all = self._tensor(("probes_all", slot), (W * B, npb), torch.int32)
+        probes_all.copy_(pack_all[:, d:])
         torch.cuda.current_stream().synchronize()  # the engine runs on its own streams; other slots keep running
         keys = self._tensor(("keys", slot), (W * B, k), torch.int64)
         ids = self._tensor(("ids", slot), (W * B, k), torch.int64)
         ds = self._tensor(("ds", slot), (W * B, k), torch.float32)
         cnt = self._tensor(("cnt", slot), (W * B,), torch.int32)
-        ctx.check(ctx.lib.fvdb_ivf_search_dev_slot(ivf._dev(), None if slot == 0 else sc.h, slot, p(q_all), W * B, k, nprobe,
-                                                   p(ids), p(ds), p(cnt), p(keys)))
+        # list scan over the lists this rank owns, for every rank's queries, with the probe lists they came with
+        ctx.check(ctx.lib.fvdb_ivf_search_probes_dev_slot(ivf._dev(), on, slot, p(q_all), p(probes_all), W * B, k, nprobe,
+                                                          p(ids), p(ds), p(cnt), p(keys)))
         hnsw.search_dev_begin(slot, p(q_local), B, d, k, ef)
         self._bufs[("state", slot)] = (q_local, B, k)
 

@@ -165,6 +165,15 @@ int fvdb_ivf_search_all(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t k, u
 int fvdb_ivf_search_dev_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t k,
                              uint32_t nprobe, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev,
                              uint64_t* out_keys_dev);
+/* The two stages separately (multi-GPU: each rank ranks the centroids for its own queries only, the probe lists
+ * travel with the queries, and every rank scans its lists for all of them).  probes: B x min(nprobe, n_clusters)
+ * cluster ids in probe order, device memory. */
+int fvdb_ivf_coarse_dev_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t nprobe,
+                             uint32_t* out_probes_dev);
+int fvdb_ivf_search_probes_dev_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev,
+                                    const uint32_t* probes_dev, uint32_t B, uint32_t k, uint32_t nprobe,
+                                    uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev,
+                                    uint64_t* out_keys_dev);
 int fvdb_ivf_search_all_dev(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t k, uint64_t* out_ids_dev,
                             float* out_dist_dev, uint32_t* out_counts_dev);
 /* Coarse step alone (src/ivf/core.rs:645-656): the nprobe nearest clusters per query in
