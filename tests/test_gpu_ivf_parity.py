@@ -200,3 +200,35 @@ def test_dot_and_cosine_utilities(fv, ctx):
             assert dots[i, j] == np.float32(orc.dot_product_scalar(qq[i], xx[j]))
             assert coss[i, j] == np.float32(orc.cosine_similarity_scalar(qq[i], xx[j]))
             assert -1.0 - 1e-6 <= coss[i, j] <= 1.0 + 1e-6
+
+
+def test_split_stages_and_slots_match_the_one_call_search(fv, ctx):
+    # fvdb_ivf_coarse_dev_slot + fvdb_ivf_search_probes_dev_slot (the multi-GPU path's two halves), on the index's own
+    # context and on a second context with another scratch slot, give exactly fvdb_ivf_search's results
+    n, d, nlist, B, k, nprobe = 30000, 64, 32, 96, 10, 6
+    x = mixture(n, d, seed=811)
+    ids = np.arange(n, dtype=np.uint64) + 11
+    cents = x[np.random.default_rng(3).choice(n, nlist, replace=False)].copy()
+    gpu, cpu, cl, pos = build_pair(fv, ctx, x, ids, cents)
+    q = mixture(B, d, seed=812)
+    want = gpu.search(q, k, nprobe)
+    assert_same(want, cpu.batch_search(q, k, nprobe))
+    lib = ctx.lib
+    other = fv.Context(0)
+    try:
+        for on, slot, c in ((None, 0, ctx), (other.h, 1, other), (other.h, 3, other)):
+            qd = c.upload(q)
+            pr, oi, od, oc = c.alloc(B * nprobe * 4), c.alloc(B * k * 8), c.alloc(B * k * 4), c.alloc(B * 4)
+            ctx.check(lib.fvdb_ivf_coarse_dev_slot(gpu.h, on, slot, qd, B, nprobe, pr))
+            ctx.check(lib.fvdb_ivf_search_probes_dev_slot(gpu.h, on, slot, qd, pr, B, k, nprobe, oi, od, oc, None))
+            c.synchronize()
+            probes = c.download(pr, (B, nprobe), np.uint32)
+            cl_want, _ = gpu.coarse(q, nprobe)
+            assert np.array_equal(probes, cl_want)
+            got = (c.download(oi, (B, k), np.uint64), c.download(od, (B, k), np.float32), c.download(oc, (B,), np.uint32))
+            assert np.array_equal(got[2], want[2]) and np.array_equal(got[0], want[0])
+            assert np.array_equal(bits(got[1]), bits(want[1]))
+            for b_ in (qd, pr, oi, od, oc):
+                c.free(b_)
+    finally:
+        other.close()
