@@ -206,6 +206,14 @@ struct fvdb_ivf : IvfScratch {
   DBuf s_fallbacks;
   int coarse_mode = 0;   // 0 = matrix cores + exact verification when applicable, 1 = exact scan only
   int scan_mode = 0;     // same choice for the inverted-list scan
+  // AUTO scan mode watches its own hit rate: the rescan counter is copied to pinned host memory behind every
+  // matrix-core batch (no sync); when too many queries of the recent batches needed the exact rescan (data the
+  // filter cannot separate, e.g. no cluster structure), the next batches go straight to the exact scan
+  HBuf h_fb;                 // pinned copy of s_fallbacks[1]
+  uint64_t mfma_q = 0;       // queries sent down the matrix-core path
+  uint64_t fb_seen = 0, q_seen = 0;  // counter / queries at the last decision
+  uint32_t exact_batches_left = 0;   // > 0: AUTO is backing off to the exact scan
+  uint32_t backoff_len = 0;
   DBuf d_xmax;           // max |x|^2 over the rows ever added (float bits)
   Pool cpool;
   DBuf c_off, c_blocks, c_glob;  // single-list table for the centroid pool
@@ -691,6 +699,10 @@ int run_fine_mfma(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint
   fm.nq = v.nfail;
   launch_merge(ctx, fm);
   if (ctx->profiling) (void)hipEventRecord(ivf->sev[5], ctx->stream);
+  // the rescan counter, for AUTO's hit-rate watch (run_fine): a 4-byte copy into pinned memory, nobody waits for it
+  HIPCHK(ctx, ivf->h_fb.ensure(64));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->h_fb.p, ivf->s_fallbacks.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+  ivf->mfma_q += B;
   HIPCHK(ctx, hipGetLastError());
   return FVDB_OK;
 }
@@ -699,8 +711,27 @@ int run_fine(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t 
              uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys, int role) {
   static const bool env_exact = getenv("FVDB_SCAN_EXACT") != nullptr;  // tuning aid
   ivf->pend_filter = false;
-  const bool mfma = ivf->scan_mode == 0 && !env_exact && role == ROLE_LIST && ivf->dpad % 16 == 0 &&
-                    k + kMfmaSlack <= 32 && np <= 256 && B >= 32 && B <= 16384 && ivf->pool.norms != nullptr;
+  bool mfma = ivf->scan_mode == 0 && !env_exact && role == ROLE_LIST && ivf->dpad % 16 == 0 &&
+              k + kMfmaSlack <= 32 && np <= 256 && B >= 32 && B <= 16384 && ivf->pool.norms != nullptr;
+  if (mfma) {
+    if (ivf->exact_batches_left > 0) {
+      ivf->exact_batches_left -= 1;
+      mfma = false;
+    } else if (ivf->h_fb.p && ivf->mfma_q - ivf->q_seen >= 2048) {
+      // rescans among the matrix-core queries since the last look (the counter lags by the batches in flight)
+      const uint64_t fb_now = *(volatile uint32_t*)ivf->h_fb.p;
+      const uint64_t dq = ivf->mfma_q - ivf->q_seen, dfb = fb_now - ivf->fb_seen;
+      ivf->q_seen = ivf->mfma_q;
+      ivf->fb_seen = fb_now;
+      if (dfb * 8 > dq) {  // more than 1 in 8: the exact scan is cheaper here; look again after a while, ever more rarely
+        ivf->backoff_len = std::min<uint32_t>(ivf->backoff_len ? ivf->backoff_len * 2 : 64, 4096);
+        ivf->exact_batches_left = ivf->backoff_len;
+        mfma = false;
+      } else {
+        ivf->backoff_len = 0;
+      }
+    }
+  }
   if (mfma) return run_fine_mfma(ivf, qpad, B, k, np, probes, out_ids, out_dist, out_counts, out_keys);
   return run_fine_exact(ivf, qpad, B, k, np, probes, out_ids, out_dist, out_counts, out_keys, role);
 }
@@ -969,6 +1000,7 @@ void fvdb_ivf_destroy(fvdb_ivf* ivf) {
   for (DBuf* b : bufs) b->release();
   ivf->release_all();
   for (auto& sp : ivf->spare) sp.release_all();
+  ivf->h_fb.release();
   delete ivf;
 }
 
@@ -1011,6 +1043,9 @@ static int install_centroids(fvdb_ivf* ivf, const float* d_rowmajor /* device [n
   hipLaunchKernelGGL(max_f32_kernel, dim3(1), dim3(64), 0, ctx->stream, ivf->d_cnorm.as<float>(), nlist,
                      ivf->d_cnmax.as<float>());
   HIPCHK(ctx, hipMemsetAsync(ivf->s_fallbacks.p, 0, 8, ctx->stream));
+  if (ivf->h_fb.p) *(volatile uint32_t*)ivf->h_fb.p = 0;
+  ivf->mfma_q = ivf->fb_seen = ivf->q_seen = 0;
+  ivf->exact_batches_left = ivf->backoff_len = 0;
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ivf->trained = true;

@@ -198,7 +198,9 @@ int fvdb_ivf_coarse_fallbacks(fvdb_ivf* ivf, uint64_t* out);
  * exact scan of the query's nearest lists plus a rounding-error bound); the few survivors are scored with the
  * reference's sequential f32 fold and selected by (distance, scan position).  A query whose k-th result is not
  * strictly below its threshold is rescanned exactly.  Results are identical to FVDB_SCAN_EXACT (every probed
- * row scored with the reference's arithmetic) by construction.  AUTO applies when padded d % 16 == 0,
+ * row scored with the reference's arithmetic) by construction.  AUTO also watches its own hit rate: when more than
+ * one query in eight of the recent batches needed the exact rescan (data the filter cannot separate), the following
+ * 64 batches (doubling up to 4096 while that stays so) use the exact scan.  AUTO applies when padded d % 16 == 0,
  * k <= 26, nprobe <= 256 and the batch has 32..16384 queries; other shapes use the exact scan. */
 #define FVDB_SCAN_AUTO 0
 #define FVDB_SCAN_EXACT 1
