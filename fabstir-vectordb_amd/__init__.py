@@ -14,5 +14,6 @@ from .engine import *  # noqa: F401,F403
 from .engine import Context, DeviceIVF, RowStore  # noqa: F401
 from .index import IVFIndex, HNSWIndex, HybridIndex, SearchResults, load_host  # noqa: F401,E402
 from . import sharded  # noqa: F401,E402
+from . import metadata_filter  # noqa: F401,E402
 from . import session  # noqa: F401,E402
 from .session import VectorDbSession, VectorId, blake3, rest_search  # noqa: F401,E402

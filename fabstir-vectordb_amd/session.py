@@ -7,8 +7,8 @@ Kept: f64 -> f32 narrowing of inputs (bindings/node/src/utils.rs:6-8), dimension
 errors, first-call initialisation with the first <= 10 vectors (session.rs:365-378), score =
 1/(1+distance) computed in f32 (session.rs:291,328; rest.rs:653), default threshold 0.0, results in
 ascending distance, `_originalId` round trip, ids shown as `vec_<8 hex of BLAKE3>` when no original id
-exists (src/core/types.rs:32-34).  Not built (out of scope): persistence, schema
-validation, metadata filters, native metadata types.
+exists (src/core/types.rs:32-34), metadata filters with 3x oversampling (metadata_filter.py).  Not built (out of
+scope): persistence, schema validation, native metadata types.
 
 `blake3()` below is written from the published BLAKE3 specification (the `blake3` crate is not
 available here); it is pinned by the official known-answer vector for the empty input.
@@ -18,6 +18,7 @@ import struct
 import numpy as np
 
 from .index import HybridIndex
+from .metadata_filter import FilterError, MetadataFilter
 
 # ---------------------------------------------------------------------------------------------
 # BLAKE3 (hash mode, 32-byte output) — VectorId::from_string (src/core/types.rs:19-22)
@@ -181,15 +182,25 @@ class VectorDbSession:
             raise SessionError(
                 f"Query vector dimension mismatch: expected {self.vector_dimension} dimensions, got {q.size}")
         threshold = np.float32(options.get("threshold", 0.0))
-        if options.get("filter") is not None:
-            raise SessionError("metadata filters are outside the accelerated path (SURVEY.md section 2, row 15)")
+        flt = None
+        if options.get("filter") is not None:  # session.rs:233-247
+            try:
+                flt = MetadataFilter.from_json(options["filter"])
+            except FilterError as e:
+                raise SessionError(f"Invalid filter: {e}") from e
+        # with a filter: 3 k candidates, keep those whose metadata match, truncate (src/hybrid/core.rs:513-549)
+        kk = int(k) * 3 if flt is not None else int(k)
         try:
-            res = self.index.search(q.reshape(1, -1), int(k), now=self.now)  # HybridIndex::search defaults (ef 50, nprobe 10)
+            res = self.index.search(q.reshape(1, -1), kk, now=self.now)  # HybridIndex::search defaults (ef 50, nprobe 10)
         except Exception as e:
             raise SessionError(f"Search failed: {e}") from e
         out = []
         ids, ds = res[0]
-        for rid, d in zip(ids.tolist(), ds.tolist()):
+        pairs = list(zip(ids.tolist(), ds.tolist()))
+        if flt is not None:
+            pairs = [(rid, d) for rid, d in pairs
+                     if self._rows.get(rid) in self.metadata and flt.matches(self.metadata[self._rows[rid]])][:int(k)]
+        for rid, d in pairs:
             score = np.float32(1.0) / (np.float32(1.0) + np.float32(d))
             if not score >= threshold:
                 continue
