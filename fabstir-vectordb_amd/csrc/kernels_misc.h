@@ -200,16 +200,35 @@ __global__ void kmeans_point_dist_kernel(const float* __restrict__ x, uint32_t d
 constexpr int kSeqTile = 8192;
 
 // total = sum_i dist_i*dist_i in index order, out[0] = total / n, out[1] = total   (src/ivf/core.rs:419-429)
+// Left-to-right f32 sum of m squares staged in LDS (already squared by all threads in parallel: the products do
+// not depend on the running sum), 16 values per trip through four 16-byte LDS reads.  One thread; same additions in
+// the same order as a scalar loop.
+__device__ __forceinline__ float seq_add16(const float* __restrict__ sq, uint32_t m, float total) {
+  uint32_t i = 0;
+  for (; i + 16 <= m; i += 16) {
+    const float4 a = *(const float4*)(sq + i), b = *(const float4*)(sq + i + 4), c = *(const float4*)(sq + i + 8),
+                 d = *(const float4*)(sq + i + 12);
+    total += a.x; total += a.y; total += a.z; total += a.w;
+    total += b.x; total += b.y; total += b.z; total += b.w;
+    total += c.x; total += c.y; total += c.z; total += c.w;
+    total += d.x; total += d.y; total += d.z; total += d.w;
+  }
+  for (; i < m; ++i) total += sq[i];
+  return total;
+}
+
 __global__ __launch_bounds__(256) void seq_sqsum_mean_kernel(const float* __restrict__ dist, uint64_t n,
                                                              float* __restrict__ out) {
-  __shared__ float tile[kSeqTile];
+  __shared__ __attribute__((aligned(16))) float tile[kSeqTile];
   float total = 0.0f;
   for (uint64_t base = 0; base < n; base += kSeqTile) {
     const uint32_t m = (uint32_t)min((uint64_t)kSeqTile, n - base);
-    for (uint32_t i = threadIdx.x; i < m; i += 256) tile[i] = dist[base + i];
+    for (uint32_t i = threadIdx.x; i < m; i += 256) {
+      const float v = dist[base + i];
+      tile[i] = v * v;
+    }
     __syncthreads();
-    if (threadIdx.x == 0)
-      for (uint32_t i = 0; i < m; ++i) total += tile[i] * tile[i];
+    if (threadIdx.x == 0) total = seq_add16(tile, m, total);
     __syncthreads();
   }
   if (threadIdx.x == 0) {
@@ -236,16 +255,18 @@ __global__ void kpp_min_dist_kernel(const float* __restrict__ x, uint32_t d, uin
 // sequential: total = sum d^2; threshold = u * total; first j with cumulative >= threshold (:357-367)
 __global__ __launch_bounds__(256) void kpp_pick_kernel(const float* __restrict__ mind, uint64_t n, float u,
                                                        unsigned long long* out_pick) {
-  __shared__ float tile[kSeqTile];
+  __shared__ __attribute__((aligned(16))) float tile[kSeqTile];
   __shared__ float s_threshold;
   __shared__ unsigned long long s_pick;
   float total = 0.0f;
   for (uint64_t base = 0; base < n; base += kSeqTile) {
     const uint32_t m = (uint32_t)min((uint64_t)kSeqTile, n - base);
-    for (uint32_t i = threadIdx.x; i < m; i += 256) tile[i] = mind[base + i];
+    for (uint32_t i = threadIdx.x; i < m; i += 256) {
+      const float v = mind[base + i];
+      tile[i] = v * v;
+    }
     __syncthreads();
-    if (threadIdx.x == 0)
-      for (uint32_t i = 0; i < m; ++i) total += tile[i] * tile[i];
+    if (threadIdx.x == 0) total = seq_add16(tile, m, total);
     __syncthreads();
   }
   if (threadIdx.x == 0) {
@@ -257,12 +278,23 @@ __global__ __launch_bounds__(256) void kpp_pick_kernel(const float* __restrict__
   for (uint64_t base = 0; base < n; base += kSeqTile) {
     if (s_pick != ~0ull) break;  // uniform: written before the barrier below
     const uint32_t m = (uint32_t)min((uint64_t)kSeqTile, n - base);
-    for (uint32_t i = threadIdx.x; i < m; i += 256) tile[i] = mind[base + i];
+    for (uint32_t i = threadIdx.x; i < m; i += 256) {
+      const float v = mind[base + i];
+      tile[i] = v * v;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
       const float threshold = s_threshold;
-      for (uint32_t i = 0; i < m; ++i) {
-        cumulative += tile[i] * tile[i];
+      // 16 at a time while the threshold is out of reach of this group (partial sums only grow: squares are >= 0),
+      // then one by one to find the first index that reaches it
+      uint32_t i = 0;
+      for (; i + 16 <= m; i += 16) {
+        const float after = seq_add16(tile + i, 16, cumulative);
+        if (after >= threshold) break;
+        cumulative = after;
+      }
+      for (; i < m; ++i) {
+        cumulative += tile[i];
         if (cumulative >= threshold) {
           s_pick = base + i;
           break;
