@@ -522,7 +522,7 @@ int run_fine_exact(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uin
 // probed lists, exact verification of the survivors, exact rescan of unproven queries.  Same outputs as
 // run_fine_exact.
 constexpr uint32_t kMfmaSlack = 6;     // phase A scores k + 6 rows
-constexpr uint32_t kMfmaCmax = 2048;   // survivor slots per query
+constexpr uint32_t kMfmaCmax = 4096;   // survivor slots per query
 namespace {
 int env_u(const char* name, int dflt) { return getenv(name) ? atoi(getenv(name)) : dflt; }
 
