@@ -406,6 +406,9 @@ def main():
         if N == 1_000_000 and nprobe == pmj.get("nprobe") and world == 1 and mfma_path:
             roofline["traffic"] = int((2 * pm["FETCH_SIZE_KB_avg"] + pm["WRITE_SIZE_KB_avg"]) * 1024)
             roofline["traffic_note"] = "bytes per launch beyond L2 (Infinity Cache + HBM), 2*FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json"
+            if scan_ms > 0:
+                roofline["traffic_GBps"] = round(roofline["traffic"] / (scan_ms * 1e-3) / 1e9, 1)
+                roofline["traffic_frac_of_hbm_peak"] = round(roofline["traffic"] / (scan_ms * 1e-3) / 1e9 / 8000.0, 4)
             roofline["pmc"] = {
                 "source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes of this command)",
                 "mfma_busy_frac_of_busy_simd_cycles": {
