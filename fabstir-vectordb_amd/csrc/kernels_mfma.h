@@ -559,6 +559,9 @@ __global__ __launch_bounds__(256) void select_kernel(const VerifyArgs m) {
   if (ath != kInf32 && ath != 0u && E < inf) {
     const float a = funmap_u32(ath);
     cut = a + 2.0f * E + 1e-6f * fabsf(a);
+    // never above the filter's own threshold: rows dropped in B only satisfy v > thr, and the bound below is stated
+    // for "every unscored row has v > cut" (a' <= a_q makes this a no-op unless the two passes rounded differently)
+    cut = fminf(cut, m.thr[q]);
   }
   uint32_t ncand = 0;
   if (proven) {
