@@ -1437,6 +1437,33 @@ int fvdb_ivf_scan_survivors(fvdb_ivf* ivf, uint32_t* out, uint32_t B) {
   return FVDB_OK;
 }
 
+int fvdb_ivf_scan_survivor_dump(fvdb_ivf* ivf, uint32_t query, uint32_t max_n, uint32_t* rank, uint32_t* pos, float* v,
+                                uint32_t* n_out) {
+  fvdb_ctx* ctx = ivf->ctx;
+  *n_out = 0;
+  if (!ivf->s_scnt.p || !ivf->s_surv.p || ivf->s_scnt.cap < (size_t)(query + 1) * 4)
+    FAIL(ctx, FVDB_E_INVALID, "no matrix-core scan holding that query has run");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  uint32_t cnt = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&cnt, ivf->s_scnt.as<uint32_t>() + query, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t n = std::min(std::min(cnt, kMfmaCmax), max_n);
+  std::vector<uint32_t> sv((size_t)n * 2);
+  if (n) {
+    HIPCHK(ctx, hipMemcpyAsync(sv.data(), (const char*)ivf->s_surv.p + (size_t)query * kMfmaCmax * 8, (size_t)n * 8,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(v, ivf->s_sdist.as<float>() + (size_t)query * kMfmaCmax, (size_t)n * 4, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  for (uint32_t i = 0; i < n; ++i) {
+    rank[i] = sv[2 * i];
+    pos[i] = sv[2 * i + 1];
+  }
+  *n_out = n;
+  return FVDB_OK;
+}
+
 int fvdb_ivf_scan_fallbacks(fvdb_ivf* ivf, uint64_t* out) {
   fvdb_ctx* ctx = ivf->ctx;
   *out = 0;

@@ -312,6 +312,16 @@ class DeviceIVF:
         self.ctx.check(self.lib.fvdb_ivf_scan_survivors(self.h, _ptr(out, u32p), B))
         return out
 
+    def scan_survivor_dump(self, query, max_n=4096):
+        """(probe rank, position in list, matrix-core value v) of one query's survivors in the last MFMA batch."""
+        rank = np.empty(max_n, np.uint32)
+        pos = np.empty(max_n, np.uint32)
+        v = np.empty(max_n, np.float32)
+        n = C.c_uint32(0)
+        self.ctx.check(self.lib.fvdb_ivf_scan_survivor_dump(self.h, query, max_n, _ptr(rank, u32p), _ptr(pos, u32p),
+                                                            _ptr(v, f32p), C.byref(n)))
+        return rank[:n.value], pos[:n.value], v[:n.value]
+
     def last_stats(self):
         st = _capi.SearchStats()
         self.ctx.check(self.lib.fvdb_ivf_last_stats(self.h, C.byref(st)))

@@ -211,6 +211,12 @@ int fvdb_ivf_scan_fallbacks(fvdb_ivf* ivf, uint64_t* out);
 /* Diagnostic: rows per query that survived the matrix-core filter in the last (sub-)batch of B queries. */
 int fvdb_ivf_scan_survivors(fvdb_ivf* ivf, uint32_t* out, uint32_t B);
 
+/* Diagnostic: the survivors of one query of the last matrix-core (sub-)batch — probe rank, position in that list and
+ * the matrix-core value v = |x|^2 - 2 x~.q~ — so that a test can hold v + |q|^2 against the reference's sum and the
+ * error bound.  At most max_n entries are written. */
+int fvdb_ivf_scan_survivor_dump(fvdb_ivf* ivf, uint32_t query, uint32_t max_n, uint32_t* rank, uint32_t* pos, float* v,
+                                uint32_t* n_out);
+
 /* Counters of the last search on this index (for roofline accounting). */
 typedef struct fvdb_search_stats {
   uint64_t rows_scanned;      /* sum over queries of rows in probed lists (algorithmic) */

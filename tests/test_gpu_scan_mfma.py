@@ -163,3 +163,42 @@ def test_short_lists_have_no_threshold(fv, ctx):
     q = mixture(50, d, seed=702)
     run_modes(gpu, cpu, q, 10, 5)
     run_modes(gpu, cpu, q, 10, 64)
+
+
+@pytest.mark.parametrize("dtype,scale", [("f32", 1.0), ("f32", 30.0), ("f16", 1.0), ("f32", 1e-3)])
+def test_matrix_core_values_stay_inside_the_error_bound(fv, ctx, dtype, scale):
+    # every survivor's v + |q|^2 must lie within E_q of the reference's f32 sum (kernels_mfma.h: mfma_error_bound) —
+    # the inequality the whole filter rests on, checked here on thousands of (row, query) pairs and several magnitudes
+    d, nlist, n, B, nprobe = 128, 16, 12000, 64, 4
+    x = (mixture(n, d, seed=901) * np.float32(scale)).astype(np.float32)
+    q = (mixture(B, d, seed=902) * np.float32(scale)).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64)
+    cents = x[np.random.default_rng(11).choice(n, nlist, replace=False)].copy()
+    gpu = fv.DeviceIVF(ctx, d, nlist, dtype=dtype) if dtype != "f32" else fv.DeviceIVF(ctx, d, nlist)
+    gpu.set_centroids(cents)
+    cl, pos = gpu.add(x, ids)
+    rows = x.astype(np.float16).astype(np.float32) if dtype == "f16" else x  # what the reference would be given
+    gpu.search(q, 10, nprobe)
+    probes, _ = gpu.coarse(q, nprobe)
+    # rows of each list in position order
+    order = np.lexsort((pos, cl))
+    start = np.searchsorted(cl[order], np.arange(nlist))
+    xmax = np.sqrt(np.max(np.sum(rows.astype(np.float64) ** 2, axis=1)))
+    u10, u11, u14, u24 = 2.0 ** -10, 2.0 ** -11, 2.0 ** -14, 2.0 ** -24
+    ux = 0.0 if dtype == "f16" else u11  # fp16 mirror of f32 rows is rounded to nearest; fp16 rows are exact
+    checked = 0
+    for b in range(B):
+        rk, ps, v = gpu.scan_survivor_dump(b)
+        if rk.size == 0:
+            continue
+        nq = np.sqrt(np.sum(q[b].astype(np.float64) ** 2))
+        E = 1.05 * (2 * (ux + u11 + ux * u11) * xmax * nq + 2 * (2 * d * u24) * xmax * nq
+                    + 1.01 * (2 * d + 16) * u24 * (xmax + nq) ** 2 + 2 * u14 * np.sqrt(d) * (xmax + nq)) \
+            + 1e-6 * (xmax + nq) ** 2
+        r = rows[order[start[probes[b, rk]] + ps]]
+        ref = orc.l2_batch(q[b], r).astype(np.float64) ** 2  # reference distances, squared back (adds <= 2^-23 relative)
+        qn = np.float32(np.sum(q[b].astype(np.float32) ** 2))
+        err = np.abs(v.astype(np.float64) + float(qn) - ref)
+        assert np.all(err <= E + 2.0 ** -22 * ref), f"query {b}: max err {err.max():.3e} > bound {E:.3e}"
+        checked += rk.size
+    assert checked > 500
