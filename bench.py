@@ -239,7 +239,7 @@ def main():
     log(f"operating point: nprobe={nprobe} ef={ef}")
 
     # ---- timed region ----
-    depth = max(1, min(args.in_flight, 4))
+    depth = max(1, min(args.in_flight, 8))
     kw = dict(now=now, hnsw_ef=ef, ivf_n_probe=nprobe, dim=d, search_recent=args.parts != "historical",
               search_historical=args.parts != "recent")
 

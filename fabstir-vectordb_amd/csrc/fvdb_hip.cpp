@@ -191,8 +191,8 @@ struct IvfScratch {
 };
 
 struct fvdb_ivf : IvfScratch {
-  static constexpr uint32_t kSlots = 4;
-  IvfScratch spare[kSlots - 1];  // slots 1..3
+  static constexpr uint32_t kSlots = 8;
+  IvfScratch spare[kSlots - 1];  // slots 1..7
   fvdb_ctx* ctx = nullptr;
   uint32_t d = 0, dpad = 0, d4 = 0, nlist = 0;
   bool trained = false;
@@ -252,9 +252,9 @@ struct fvdb_graph {
   DBuf d_level, d_deleted, d_slot_of, d_slot_start, d_adj, d_adj0;
   uint32_t stride0 = 0;
   DBuf s_q, d_counters;
-  static constexpr uint32_t kSlots = 4;  // batches that may be in flight at once, each on its own stream
+  static constexpr uint32_t kSlots = 8;  // batches that may be in flight at once, each on its own stream
   DBuf s_visited[kSlots], s_touched[kSlots];
-  uint32_t vis_B[kSlots] = {0, 0, 0, 0}, vis_words = 0, vis_tcap = 0;
+  uint32_t vis_B[kSlots] = {0, 0, 0, 0, 0, 0, 0, 0}, vis_words = 0, vis_tcap = 0;
   bool uploaded = false;
   // profiling: HIP events around the last launches of the traversal kernel (ring of 64)
   std::vector<uint8_t> h_deleted;  // host copy of the flags: searches skip the per-neighbour flag load when none is set
@@ -1928,8 +1928,9 @@ void fvdb_graph_destroy(fvdb_graph* g) {
   if (!g) return;
   (void)hipSetDevice(g->store->ctx->device);
   (void)hipStreamSynchronize(g->store->ctx->stream);
-  DBuf* bufs[] = {&g->d_level, &g->d_deleted, &g->d_slot_of, &g->d_slot_start, &g->d_adj, &g->d_adj0, &g->s_q, &g->d_counters, &g->s_visited[0], &g->s_visited[1], &g->s_visited[2], &g->s_visited[3],
-                  &g->s_touched[0], &g->s_touched[1], &g->s_touched[2], &g->s_touched[3]};
+  DBuf* bufs[] = {&g->d_level, &g->d_deleted, &g->d_slot_of, &g->d_slot_start, &g->d_adj, &g->d_adj0, &g->s_q, &g->d_counters};
+  for (auto& b : g->s_visited) b.release();
+  for (auto& b : g->s_touched) b.release();
   for (DBuf* b : bufs) b->release();
   delete g;
 }

@@ -315,7 +315,7 @@ class HNSWIndex(_Base):
         return SearchResults(ids, ds, cnt)
 
     def search_dev_begin(self, slot, q_dev, B, dim, k, ef):
-        """Enqueue the device traversal of a batch in `slot` (0..3); the query buffer must stay valid until
+        """Enqueue the device traversal of a batch in `slot` (0..7); the query buffer must stay valid until
         search_dev_end(slot)."""
         rc = self.lib.fvh_hnsw_search_dev_begin(self.h, slot, q_dev, B, dim, k, ef)
         if rc < 0:
@@ -494,7 +494,7 @@ class HybridIndex(_Base):
                                                    _ptr(ids, u64p), _ptr(ds, f32p), _ptr(cnt, u32p)))
         return SearchResults(ids, ds, cnt)
 
-    SLOTS = 4
+    SLOTS = 8
 
     def search_dev_begin(self, slot, q_dev, B, k, now=0.0, hnsw_ef=50, ivf_n_probe=10, search_recent=True,
                          search_historical=True, recent_k=0, historical_k=0, dim=None):

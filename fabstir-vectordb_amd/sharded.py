@@ -137,7 +137,7 @@ class ShardedHybrid:
         """This rank's B x d f32 query batch as a device tensor (kept by the caller across steps)."""
         return self.torch.from_numpy(np.ascontiguousarray(q, np.float32)).cuda()
 
-    SLOTS = 4
+    SLOTS = 8
 
     def _slot_ctx(self, slot):
         """Engine context (stream) of the slot's IVF chain: slot 0 = the index's own."""
