@@ -317,6 +317,14 @@ class HybridIndex {
   int search_dev_begin(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
                        double now);
   int search_dev_end(uint32_t slot, uint64_t* ids, float* dist, uint32_t* counts);
+  bool busy() const {  // some batch is in flight: inserts / deletes are refused until it is collected
+    for (const Slot& s : slots_)
+      if (s.active) return true;
+    return false;
+  }
+  bool migration_due(double threshold_s, double now) const {
+    return !pending_migration_.empty() && age_of(now, pending_min_ts_) >= threshold_s;
+  }
   uint64_t migrate_with_threshold(double threshold_s, double now);                                // :600
   int remove(uint64_t id, double now);                                                             // delete :904
   uint64_t recent_count() const { return recent_count_; }

@@ -52,6 +52,7 @@ int HybridIndex::set_ivf_centroids(const float* c, uint32_t dim) {
 int HybridIndex::insert_with_timestamp(uint64_t id, const float* v, uint32_t dim, double ts, double now,
                                        int64_t level) {
   if (!initialized_) return FVDB_E_NOT_INITIALIZED;
+  if (busy()) return FVDB_E_INVALID;  // a search begun with search_dev_begin has not been collected yet
   if (timestamps_.count(id)) return FVDB_E_DUPLICATE;
   bool to_recent = !ivf_trained_ || age_of(now, ts) < cfg_.recent_threshold_s;
   if (to_recent) {
@@ -75,7 +76,7 @@ int HybridIndex::insert_with_timestamp(uint64_t id, const float* v, uint32_t dim
 int HybridIndex::bulk_insert(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const double* ts,
                              double now) {
   if (!initialized_) return FVDB_E_NOT_INITIALIZED;
-  if (!ts_order_.empty()) return FVDB_E_INVALID;
+  if (!ts_order_.empty() || busy()) return FVDB_E_INVALID;
   std::vector<uint64_t> rid, hid;
   std::vector<float> rv, hv;
   for (uint64_t i = 0; i < n; ++i) {
@@ -129,7 +130,7 @@ static void plan_list_owners(const std::vector<uint64_t>& sizes, uint32_t world,
 int HybridIndex::bulk_insert_sharded(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const double* ts,
                                      double now, uint32_t rank, uint32_t world, uint32_t* owner_out) {
   if (!initialized_) return FVDB_E_NOT_INITIALIZED;
-  if (!ts_order_.empty() || world == 0 || rank >= world) return FVDB_E_INVALID;
+  if (!ts_order_.empty() || world == 0 || rank >= world || busy()) return FVDB_E_INVALID;
   std::vector<uint64_t> rid, hid;
   std::vector<float> rv, hv;
   for (uint64_t i = 0; i < n; ++i) {
@@ -188,7 +189,7 @@ uint64_t HybridIndex::migrate_with_threshold(double threshold_s, double now) {
   // The reference walks the whole timestamps map on every search (:606-617).  Same outcome, O(1) when
   // nothing is due: only ids still living in HNSW alone can migrate, and none is due while the oldest
   // of them is younger than the threshold.
-  if (pending_migration_.empty() || age_of(now, pending_min_ts_) < threshold_s) return 0;
+  if (!migration_due(threshold_s, now) || busy()) return 0;
   std::vector<Pending> keep;
   std::vector<uint64_t> due;
   double min_ts = 1e300;
@@ -267,6 +268,9 @@ int HybridIndex::search_dev_begin(uint32_t slot, const float* q_dev, uint32_t B,
   if (slot >= kSlots) return FVDB_E_INVALID;
   Slot& sl = slots_[slot];
   if (sl.active) return FVDB_E_INVALID;  // the previous batch of this slot was never collected
+  // a due migration moves rows between the two indexes (and may grow the list pool) under the batches still in
+  // flight: refuse, the caller collects them and begins again
+  if (initialized_ && cfg_.auto_migrate && busy() && migration_due(cfg_.recent_threshold_s, now)) return FVDB_E_INVALID;
   sl = Slot{sl.d_hid, sl.d_hd, sl.d_hc, sl.h_hid, sl.h_hd, sl.h_hc, sl.cap, sl.ivf_done, sl.ivf_ctx};
   sl.q = q_dev;
   sl.B = B;
@@ -397,6 +401,7 @@ int HybridIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint3
 
 // delete: src/hybrid/core.rs:904-937
 int HybridIndex::remove(uint64_t id, double now) {
+  if (busy()) return FVDB_E_INVALID;  // a search begun with search_dev_begin has not been collected yet
   auto it = timestamps_.find(id);
   if (it == timestamps_.end()) return FVDB_E_NOT_FOUND;
   if (age_of(now, it->second) < cfg_.recent_threshold_s) return recent_->mark_deleted(id);

@@ -500,7 +500,8 @@ class HybridIndex(_Base):
                          search_historical=True, recent_k=0, historical_k=0, dim=None):
         """Enqueue a batch search in `slot` (0..SLOTS-1) and return at once; several slots may be in flight together
         (the graph walk of one batch uses one wavefront per SIMD, so a second batch's walk runs beside it).  The
-        query buffer must stay valid until search_dev_end(slot); no inserts/deletes in between."""
+        query buffer must stay valid until search_dev_end(slot).  Inserts, deletes and migrations are refused (status
+        INVALID) while any slot is in flight, and so is a begin whose `now` makes an auto-migration due."""
         self._check(self.lib.fvh_hybrid_search_dev_begin(self.h, slot, q_dev, B, dim, k, hnsw_ef, ivf_n_probe,
                                                          int(search_recent), int(search_historical), recent_k,
                                                          historical_k, float(now)))

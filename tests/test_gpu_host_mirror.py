@@ -408,3 +408,33 @@ def test_hybrid_batches_in_flight_match_one_at_a_time(fv, ctx):
         ro = o.search(batches[0][b], 10, now=now, hnsw_ef=30, ivf_n_probe=4)
         assert r.counts[b] == len(ro) and np.array_equal(r.ids[b, : len(ro)], ro.ids)
         assert np.array_equal(bits(r.distances[b, : len(ro)]), bits(np.asarray(ro.distances, np.float32)))
+
+
+def test_hybrid_refuses_mutation_while_a_batch_is_in_flight(fv, ctx):
+    # inserts, deletes and migrations move rows (and may grow the list pool) under a scan that is still running:
+    # they are refused until every begun batch has been collected, and work again afterwards
+    n, d, nlist = 600, 32, 8
+    x = mixture(n, d, n_comp=8, seed=95)
+    now = 1000 * DAY
+    g = fv.HybridIndex(ctx, max_connections=8, max_connections_layer_0=16, ef_construction=40, n_clusters=nlist, n_probe=4)
+    g.set_ivf_centroids(x[:nlist].copy())
+    for i in range(n):
+        g.insert_with_timestamp(i, x[i], now - (1 if i % 3 else 30) * DAY, now)
+    q = g.ctx.upload(mixture(32, d, n_comp=8, seed=96))
+    want = g.search_dev(q, 32, 5, now=now, hnsw_ef=30, ivf_n_probe=4, dim=d)
+    g.search_dev_begin(0, q, 32, 5, now=now, hnsw_ef=30, ivf_n_probe=4, dim=d)
+    with pytest.raises(fv.FvdbError):
+        g.insert_with_timestamp(n, x[0] + 1, now, now)
+    with pytest.raises(fv.FvdbError):
+        g.delete(3, now)
+    assert g.migrate_with_threshold(0.5 * DAY, now) == 0
+    with pytest.raises(fv.FvdbError):  # a later `now` makes a migration due: slot 1 may not begin under slot 0
+        g.search_dev_begin(1, q, 32, 5, now=now + 10 * DAY, hnsw_ef=30, ivf_n_probe=4, dim=d)
+    g._inflight.pop(1, None)
+    rc, hc = g.recent_count(), g.historical_count()
+    got = g.search_dev_end(0)
+    assert np.array_equal(got.ids, want.ids) and np.array_equal(bits(got.distances), bits(want.distances))
+    assert (g.recent_count(), g.historical_count()) == (rc, hc)
+    g.insert_with_timestamp(n, x[0] + 1, now, now)
+    g.delete(3, now)
+    assert g.migrate_with_threshold(0.5 * DAY, now) > 0
