@@ -17,3 +17,4 @@ from . import sharded  # noqa: F401,E402
 from . import metadata_filter  # noqa: F401,E402
 from . import session  # noqa: F401,E402
 from .session import VectorDbSession, VectorId, blake3, rest_search  # noqa: F401,E402
+from . import chunked  # noqa: F401,E402

@@ -50,6 +50,7 @@ SIGNATURES = {
     "fvdb_ivf_add_assigned": (i32, [vp, f32p, u64p, u64, u32p, u32p]),
     "fvdb_ivf_set_deleted": (i32, [vp, u32p, u32p, u64, i32]),
     "fvdb_ivf_list_sizes": (i32, [vp, u64p]),
+    "fvdb_ivf_list_export": (i32, [vp, u32, f32p, u64p, C.POINTER(C.c_uint8)]),
     "fvdb_ivf_total_rows": (u64, [vp]),
     "fvdb_ivf_reserve": (i32, [vp, u64]),
     "fvdb_ivf_clear": (i32, [vp]),

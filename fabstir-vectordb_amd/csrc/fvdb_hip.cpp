@@ -1105,6 +1105,45 @@ int fvdb_ivf_list_sizes(fvdb_ivf* ivf, uint64_t* out) {
 }
 uint64_t fvdb_ivf_total_rows(fvdb_ivf* ivf) { return ivf->total_rows; }
 
+// Copy one inverted list back to the host in list-position order (the save path of the chunked on-disk format,
+// src/hybrid/persistence.rs:289-311 walks every inverted list).  fp16 rows are widened exactly.
+int fvdb_ivf_list_export(fvdb_ivf* ivf, uint32_t list, float* rows, uint64_t* ids, uint8_t* live) {
+  fvdb_ctx* ctx = ivf->ctx;
+  if (list >= ivf->nlist) FAIL(ctx, FVDB_E_INVALID, "no such list");
+  const uint32_t len = ivf->list_len[list];
+  if (len == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const Pool& P = ivf->pool;
+  const size_t bb = P.block_bytes();
+  std::vector<uint8_t> blk(bb);
+  uint64_t bid[64], valid = 0;
+  const uint32_t d = ivf->d;
+  for (uint32_t b = 0; b * 64 < len; ++b) {
+    const uint32_t pb = ivf->list_blocks[list][b];
+    HIPCHK(ctx, hipMemcpyAsync(blk.data(), (const char*)P.data + (size_t)pb * bb, bb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(bid, P.ids + (size_t)pb * 64, sizeof bid, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&valid, P.valid + pb, sizeof valid, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t rows_here = std::min<uint32_t>(64, len - b * 64);
+    for (uint32_t lane = 0; lane < rows_here; ++lane) {
+      const size_t r = (size_t)b * 64 + lane;
+      if (rows) {
+        float* out = rows + r * d;
+        if (P.esize == 4) {  // [d4][64] chunks of 4 floats, lane = row
+          const float* src = (const float*)blk.data();
+          for (uint32_t j = 0; j < d; ++j) out[j] = src[((size_t)(j >> 2) * 64 + lane) * 4 + (j & 3)];
+        } else {  // [d8][64] chunks of 8 halves
+          const _Float16* src = (const _Float16*)blk.data();
+          for (uint32_t j = 0; j < d; ++j) out[j] = (float)src[((size_t)(j >> 3) * 64 + lane) * 8 + (j & 7)];
+        }
+      }
+      if (ids) ids[r] = bid[lane];
+      if (live) live[r] = (uint8_t)((valid >> lane) & 1);
+    }
+  }
+  return FVDB_OK;
+}
+
 int fvdb_ivf_set_global_list_sizes(fvdb_ivf* ivf, const uint64_t* sizes) {
   ivf->glob_blocks_host.resize(ivf->nlist);
   for (uint32_t L = 0; L < ivf->nlist; ++L) ivf->glob_blocks_host[L] = cdiv(sizes[L], 64);

@@ -245,6 +245,15 @@ class DeviceIVF:
         self.ctx.check(self.lib.fvdb_ivf_list_sizes(self.h, _ptr(out, u64p)))
         return out
 
+    def list_export(self, c):
+        """Rows (f32), ids and live flags of list `c` in list-position order, copied back from HBM."""
+        import ctypes as C
+        n = int(self.list_sizes()[c])
+        rows, ids, live = np.empty((n, self.d), np.float32), np.empty(n, np.uint64), np.empty(n, np.uint8)
+        self.ctx.check(self.lib.fvdb_ivf_list_export(self.h, int(c), _ptr(rows, f32p), _ptr(ids, u64p),
+                                                     live.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return rows, ids, live.astype(bool)
+
     def total_rows(self):
         return int(self.lib.fvdb_ivf_total_rows(self.h))
 

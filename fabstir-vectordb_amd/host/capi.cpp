@@ -31,6 +31,9 @@ uint32_t fvh_ivf_dimension(void* p) { return ((IVFIndex*)p)->dimension(); }
 uint64_t fvh_ivf_total_vectors(void* p) { return ((IVFIndex*)p)->total_vectors(); }
 uint64_t fvh_ivf_active_count(void* p) { return ((IVFIndex*)p)->active_count(); }
 uint64_t fvh_ivf_cluster_size(void* p, uint32_t c) { return ((IVFIndex*)p)->cluster_size(c); }
+int fvh_ivf_export_list(void* p, uint32_t c, float* rows, uint64_t* ids, uint8_t* live) {
+  return ((IVFIndex*)p)->export_list(c, rows, ids, live);
+}
 int fvh_ivf_insert(void* p, uint64_t id, const float* v, uint32_t d) { return ((IVFIndex*)p)->insert(id, v, d); }
 int fvh_ivf_batch_insert(void* p, const uint64_t* ids, const float* v, uint64_t n, uint32_t d, uint64_t* n_ok,
                          int* first_error) {
@@ -218,6 +221,12 @@ int fvh_hybrid_delete(void* p, uint64_t id, double now) { return ((HybridIndex*)
 uint64_t fvh_hybrid_migrate(void* p, double thr, double now) {
   return ((HybridIndex*)p)->migrate_with_threshold(thr, now);
 }
+int fvh_hybrid_from_parts(void* p, const uint64_t* ids, const double* ts, uint64_t n, uint64_t recent_count,
+                          uint64_t historical_count, int ivf_trained) {
+  return ((HybridIndex*)p)->from_parts(ids, ts, n, recent_count, historical_count, ivf_trained != 0);
+}
+uint64_t fvh_hybrid_timestamp_count(void* p) { return ((HybridIndex*)p)->timestamp_count(); }
+void fvh_hybrid_export_timestamps(void* p, uint64_t* ids, double* ts) { ((HybridIndex*)p)->export_timestamps(ids, ts); }
 uint64_t fvh_hybrid_recent_count(void* p) { return ((HybridIndex*)p)->recent_count(); }
 uint64_t fvh_hybrid_historical_count(void* p) { return ((HybridIndex*)p)->historical_count(); }
 int fvh_hybrid_is_initialized(void* p) { return ((HybridIndex*)p)->is_initialized(); }

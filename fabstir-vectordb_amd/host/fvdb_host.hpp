@@ -97,6 +97,8 @@ class IVFIndex {
   bool is_deleted(uint64_t id) const { return deleted_.count(id) > 0; }
   uint64_t active_count() const { return total_ - deleted_.size(); }
   uint64_t cluster_size(uint32_t c) const;
+  // list `c` in list-position order, copied back from HBM (save path, src/hybrid/persistence.rs:289-311)
+  int export_list(uint32_t c, float* rows, uint64_t* ids, uint8_t* live) const;
   void clear_lists();                                                             // hybrid initialize :278-287
   fvdb_ivf* device() { return dev_; }
 
@@ -329,6 +331,13 @@ class HybridIndex {
   int remove(uint64_t id, double now);                                                             // delete :904
   uint64_t recent_count() const { return recent_count_; }
   uint64_t historical_count() const { return historical_count_; }
+  // from_parts (src/hybrid/core.rs:857-877): adopt the two indexes as they now are (the caller has restored the
+  // graph into recent() and set_trained + inserted the lists of historical()) together with the saved timestamp
+  // table and counters; the index becomes initialised.  Only valid while the timestamp table is empty.
+  int from_parts(const uint64_t* ids, const double* ts, uint64_t n, uint64_t recent_count, uint64_t historical_count,
+                 bool ivf_trained);
+  uint64_t timestamp_count() const { return ts_order_.size(); }
+  void export_timestamps(uint64_t* ids, double* ts) const;  // insertion order
   HNSWIndex& recent() { return *recent_; }
   IVFIndex& historical() { return *historical_; }
   // bulk loaders for scale runs: route by age like insert_with_timestamp, batched on the GPU

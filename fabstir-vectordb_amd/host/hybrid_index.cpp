@@ -185,6 +185,35 @@ int HybridIndex::bulk_insert_sharded(const uint64_t* ids, const float* v, uint64
 }
 
 // src/hybrid/core.rs:600-649 — copies into IVF, never removes from HNSW (:577-581)
+// src/hybrid/core.rs:857-877
+int HybridIndex::from_parts(const uint64_t* ids, const double* ts, uint64_t n, uint64_t recent_count,
+                            uint64_t historical_count, bool ivf_trained) {
+  if (!ts_order_.empty() || busy()) return FVDB_E_INVALID;
+  if (ivf_trained && !historical_->is_trained()) return FVDB_E_NOT_TRAINED;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (!timestamps_.emplace(ids[i], ts[i]).second) continue;  // a map on disk holds each key once; keep the first
+    ts_order_.push_back(ids[i]);
+    // ids with a node in the graph are what migrate_with_threshold can still copy into IVF (:626 get_node); one
+    // already in a list fails there as a duplicate and leaves the queue, as on every search of the reference
+    if (recent_->vector_of(ids[i])) {
+      pending_migration_.push_back({ids[i], ts[i]});
+      pending_min_ts_ = std::min(pending_min_ts_, ts[i]);
+    }
+  }
+  recent_count_ = recent_count;
+  historical_count_ = historical_count;
+  ivf_trained_ = ivf_trained;
+  initialized_ = true;
+  return FVDB_OK;
+}
+
+void HybridIndex::export_timestamps(uint64_t* ids, double* ts) const {
+  for (size_t i = 0; i < ts_order_.size(); ++i) {
+    ids[i] = ts_order_[i];
+    ts[i] = timestamps_.at(ts_order_[i]);
+  }
+}
+
 uint64_t HybridIndex::migrate_with_threshold(double threshold_s, double now) {
   // The reference walks the whole timestamps map on every search (:606-617).  Same outcome, O(1) when
   // nothing is due: only ids still living in HNSW alone can migrate, and none is due while the oldest

@@ -63,6 +63,12 @@ void IVFIndex::clear_lists() {
   total_ = 0;
 }
 
+int IVFIndex::export_list(uint32_t c, float* rows, uint64_t* ids, uint8_t* live) const {
+  if (c >= cfg_.n_clusters) return FVDB_E_INVALID;
+  if (!dev_) return FVDB_OK;  // nothing stored yet
+  return fvdb_ivf_list_export(dev_, c, rows, ids, live);
+}
+
 uint64_t IVFIndex::cluster_size(uint32_t c) const {
   if (!dev_ || c >= cfg_.n_clusters) return 0;
   std::vector<uint64_t> sizes(cfg_.n_clusters);

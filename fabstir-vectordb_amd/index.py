@@ -34,6 +34,7 @@ HOST_SIGNATURES = {
     "fvh_ivf_total_vectors": (u64, [vp]),
     "fvh_ivf_active_count": (u64, [vp]),
     "fvh_ivf_cluster_size": (u64, [vp, u32]),
+    "fvh_ivf_export_list": (i32, [vp, u32, f32p, u64p, C.POINTER(C.c_uint8)]),
     "fvh_ivf_insert": (i32, [vp, u64, f32p, u32]),
     "fvh_ivf_batch_insert": (i32, [vp, u64p, f32p, u64, u32, u64p, C.POINTER(i32)]),
     "fvh_ivf_find_cluster": (i32, [vp, f32p, u32, u32p]),
@@ -83,6 +84,9 @@ HOST_SIGNATURES = {
     "fvh_hnsw_search_dev_end": (i32, [vp, u32, vp, u32, u32, u32, u32, u64p, f32p, u32p]),
     "fvh_hybrid_delete": (i32, [vp, u64, dbl]),
     "fvh_hybrid_migrate": (u64, [vp, dbl, dbl]),
+    "fvh_hybrid_from_parts": (i32, [vp, u64p, f64p, u64, u64, u64, i32]),
+    "fvh_hybrid_timestamp_count": (u64, [vp]),
+    "fvh_hybrid_export_timestamps": (None, [vp, u64p, f64p]),
     "fvh_hybrid_recent_count": (u64, [vp]),
     "fvh_hybrid_historical_count": (u64, [vp]),
     "fvh_hybrid_is_initialized": (i32, [vp]),
@@ -228,6 +232,14 @@ class IVFIndex(_Base):
 
     def get_cluster_size(self, c):
         return int(self.lib.fvh_ivf_cluster_size(self.h, c))
+
+    def export_list(self, c):
+        """Rows (f32), ids and live flags of inverted list `c`, in list-position order (save path)."""
+        n = self.get_cluster_size(c)
+        rows, ids, live = np.empty((n, max(self.dimension(), 1)), np.float32), np.empty(n, np.uint64), np.empty(n, np.uint8)
+        self._check(self.lib.fvh_ivf_export_list(self.h, int(c), _ptr(rows, f32p), _ptr(ids, u64p),
+                                                 live.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return rows, ids, live.astype(bool)
 
     def search(self, queries, k, n_probe=None):
         return self._search(self.lib.fvh_ivf_search, queries, k, self.n_probe if n_probe is None else n_probe)
@@ -422,6 +434,11 @@ class HybridIndex(_Base):
         self.ctx, self.lib = ctx, load_host()
         self.ctx_hnsw = ctx_hnsw or ctx
         self.n_clusters, self.n_probe = n_clusters, n_probe
+        self.config = dict(recent_threshold=recent_threshold, migration_batch_size=migration_batch_size,
+                           auto_migrate=auto_migrate, min_ivf_training_size=min_ivf_training_size,
+                           max_connections=max_connections, max_connections_layer_0=max_connections_layer_0,
+                           ef_construction=ef_construction, hnsw_seed=hnsw_seed, n_clusters=n_clusters, n_probe=n_probe,
+                           train_size=train_size, max_iterations=max_iterations, ivf_seed=ivf_seed)
         self.h = self.lib.fvh_hybrid_new(ctx.h, self.ctx_hnsw.h, recent_threshold, migration_batch_size,
                                          int(auto_migrate), min_ivf_training_size, max_connections,
                                          max_connections_layer_0, ef_construction, hnsw_seed, n_clusters, n_probe,
@@ -519,6 +536,19 @@ class HybridIndex(_Base):
 
     def delete(self, id, now=0.0):
         self._check(self.lib.fvh_hybrid_delete(self.h, int(id), float(now)))
+
+    def from_parts(self, ids, timestamps, recent_count, historical_count, ivf_trained):
+        """HybridIndex::from_parts (src/hybrid/core.rs:857-877): adopt hnsw() / ivf() as restored by the caller."""
+        ids = np.ascontiguousarray(ids, np.uint64)
+        ts = np.ascontiguousarray(timestamps, np.float64)
+        self._check(self.lib.fvh_hybrid_from_parts(self.h, _ptr(ids, u64p), _ptr(ts, f64p), ids.size, int(recent_count),
+                                                   int(historical_count), int(bool(ivf_trained))))
+
+    def export_timestamps(self):
+        n = int(self.lib.fvh_hybrid_timestamp_count(self.h))
+        ids, ts = np.empty(n, np.uint64), np.empty(n, np.float64)
+        self.lib.fvh_hybrid_export_timestamps(self.h, _ptr(ids, u64p), _ptr(ts, f64p))
+        return ids, ts
 
     def migrate_with_threshold(self, threshold, now):
         return int(self.lib.fvh_hybrid_migrate(self.h, float(threshold), float(now)))

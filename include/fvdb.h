@@ -139,6 +139,10 @@ int fvdb_ivf_add_assigned(fvdb_ivf* ivf, const float* x, const uint64_t* ids, ui
 int fvdb_ivf_set_deleted(fvdb_ivf* ivf, const uint32_t* cluster, const uint32_t* pos, uint64_t n, int deleted);
 int fvdb_ivf_list_sizes(fvdb_ivf* ivf, uint64_t* out /* nlist */);
 uint64_t fvdb_ivf_total_rows(fvdb_ivf* ivf);
+/* Copy list `list` back to the host in list-position order: rows [len x d] as f32 (fp16 rows widened exactly), ids
+ * [len], live [len] (0 = soft-deleted).  Any output may be NULL.  len = fvdb_ivf_list_sizes()[list].  Replaces the
+ * walk over `InvertedList.vectors` of the reference's save path (src/hybrid/persistence.rs:289-311). */
+int fvdb_ivf_list_export(fvdb_ivf* ivf, uint32_t list, float* rows, uint64_t* ids, uint8_t* live);
 int fvdb_ivf_reserve(fvdb_ivf* ivf, uint64_t n_rows);
 int fvdb_ivf_clear(fvdb_ivf* ivf);   /* empties the lists, keeps centroids (hybrid initialize :278-287) */
 /* Multi-GPU: sizes of ALL lists of the logical index (this rank may own a subset), so the

@@ -1,0 +1,272 @@
+"""The reference's chunked on-disk format (fabstir-vectordb_amd/chunked.py).
+
+CPU: the CBOR codec against RFC 8949 Appendix A's examples (the published known answers — no file written by the
+Rust code exists on this box), serde's shapes for the reference's structs, the manifest rules the reference's tests
+pin (tests/integration/manifest_version_tests.rs).  GPU: save -> load round trip with identical search results and
+the behaviours of tests/integration/chunked_{save,load}_tests.rs.
+"""
+import json
+
+import numpy as np
+import pytest
+
+import fvdb_import
+from _data import bits, mixture
+
+fv = fvdb_import.load()
+ck = fv.chunked
+DAY = 86400.0
+
+# RFC 8949 Appendix A (diagnostic value, hex encoding)
+RFC = [(0, "00"), (1, "01"), (10, "0a"), (23, "17"), (24, "1818"), (25, "1819"), (100, "1864"), (1000, "1903e8"),
+       (1000000, "1a000f4240"), (1000000000000, "1b000000e8d4a51000"), (18446744073709551615, "1bffffffffffffffff"),
+       (-1, "20"), (-10, "29"), (-100, "3863"), (-1000, "3903e7"),
+       (0.0, "f90000"), (-0.0, "f98000"), (1.0, "f93c00"), (1.1, "fb3ff199999999999a"), (1.5, "f93e00"),
+       (65504.0, "f97bff"), (100000.0, "fa47c35000"), (3.4028234663852886e+38, "fa7f7fffff"),
+       (1.0e+300, "fb7e37e43c8800759c"), (5.960464477539063e-8, "f90001"), (0.00006103515625, "f90400"),
+       (-4.0, "f9c400"), (-4.1, "fbc010666666666666"), (float("inf"), "f97c00"), (float("-inf"), "f9fc00"),
+       (False, "f4"), (True, "f5"), (None, "f6"),
+       (b"", "40"), (b"\x01\x02\x03\x04", "4401020304"), ("", "60"), ("a", "6161"), ("IETF", "6449455446"),
+       ("\"\\", "62225c"), ("ü", "62c3bc"), ("水", "63e6b0b4"),
+       ([], "80"), ([1, 2, 3], "83010203"), ([1, [2, 3], [4, 5]], "8301820203820405"),
+       (list(range(1, 26)), "98190102030405060708090a0b0c0d0e0f101112131415161718181819"),
+       ({}, "a0"), ({1: 2, 3: 4}, "a201020304"), ({"a": 1, "b": [2, 3]}, "a26161016162820203"),
+       (["a", {"b": "c"}], "826161a161626163"),
+       ({"a": "A", "b": "B", "c": "C", "d": "D", "e": "E"}, "a56161614161626142616361436164614461656145")]
+
+
+def test_cbor_rfc8949_appendix_a():
+    for value, hexed in RFC:
+        assert ck.cbor_encode(value).hex() == hexed, value
+        got = ck.cbor_decode(bytes.fromhex(hexed))
+        if isinstance(value, float):
+            assert isinstance(got, float) and got == value and np.signbit(got) == np.signbit(value), (value, got)
+        else:
+            assert got == value and type(got) is type(value), (value, got)
+    # decoder-only forms: NaN, indefinite lengths, tags, f64 NaN
+    assert np.isnan(ck.cbor_decode(bytes.fromhex("f97e00"))) and np.isnan(ck.cbor_decode(bytes.fromhex("fb7ff8000000000000")))
+    assert ck.cbor_encode(float("nan")).hex() == "f97e00"
+    assert ck.cbor_decode(bytes.fromhex("5f42010243030405ff")) == b"\x01\x02\x03\x04\x05"
+    assert ck.cbor_decode(bytes.fromhex("7f657374726561646d696e67ff")) == "streaming"
+    assert ck.cbor_decode(bytes.fromhex("9fff")) == []
+    assert ck.cbor_decode(bytes.fromhex("9f018202039f0405ffff")) == [1, [2, 3], [4, 5]]
+    assert ck.cbor_decode(bytes.fromhex("bf61610161629f0203ffff")) == {"a": 1, "b": [2, 3]}
+    assert ck.cbor_decode(bytes.fromhex("c11a514b67b0")) == 1363896240
+    for bad in ("18", "8301", "a161", "ff", "0001", "1c"):
+        with pytest.raises(ValueError):
+            ck.cbor_decode(bytes.fromhex(bad))
+
+
+def test_f32_arrays_take_the_shortest_exact_form():
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal(1000).astype(np.float32)
+    a[::7] = np.round(a[::7] * 4) / 4          # exactly representable in f16
+    a[5], a[6], a[8] = np.inf, -np.inf, 65504.0
+    a[9] = np.float32(1e-8)                     # below the f16 subnormal range: stays f32
+    enc = ck.encode_f32_array(a)
+    assert enc == ck._head(4, a.size) + b"".join(ck.cbor_encode(np.float32(x)) for x in a)  # vectorised == item by item
+    dec = ck.cbor_decode(enc)
+    assert dec.dtype == np.float32 and np.array_equal(bits(dec), bits(a))
+    # all-f32 and all-f16 arrays take the strided fast paths
+    b = rng.standard_normal(384).astype(np.float32)
+    assert len(ck.encode_f32_array(b)) == 3 + 5 * 384 and np.array_equal(bits(ck.cbor_decode(ck.encode_f32_array(b))), bits(b))
+    c = np.arange(64, dtype=np.float32)
+    assert len(ck.encode_f32_array(c)) == 2 + 3 * 64 and np.array_equal(ck.cbor_decode(ck.encode_f32_array(c)), c)
+    d = np.asarray([np.nan, 1.5], np.float32)
+    assert ck.encode_f32_array(d).hex() == "82f97e00f93e00"
+
+
+def test_vector_chunk_shape_and_round_trip():
+    # VectorChunk{chunk_id, start_idx, end_idx, vectors} (src/core/chunk.rs:36-42): map keyed by field name, the
+    # vectors map keyed by 32-integer arrays
+    ids = [ck.VectorIdBytes(fv.blake3(f"vec{i}".encode())) for i in range(3)]
+    rows = [np.asarray([1.0, 2.0, 3.0], np.float32), np.asarray([0.1, 0.2, 0.3], np.float32), np.zeros(3, np.float32)]
+    data = ck.cbor_encode({"chunk_id": "chunk-0", "start_idx": 0, "end_idx": 2, "vectors": ck.PairMap(list(zip(ids, rows)))})
+    assert data[:10] == bytes.fromhex("a4") + bytes.fromhex("68") + b"chunk_id"
+    key = bytes.fromhex("9820") + b"".join(bytes([b]) if b < 24 else bytes([0x18, b]) for b in ids[0])
+    assert key in data and bytes.fromhex("83f93c00f94000f94200") in data  # [1.0, 2.0, 3.0] as three f16
+    cid, s, e, got_ids, got_rows = ck.read_chunk(data)
+    assert (cid, s, e) == ("chunk-0", 0, 2) and got_ids == [bytes(i) for i in ids]
+    assert all(np.array_equal(bits(a), bits(b)) for a, b in zip(got_rows, rows))
+    assert ck.display_id(ids[0]).startswith("vec_") and len(ck.display_id(ids[0])) == 12
+    # an empty chunk, a missing field, a short id
+    assert ck.read_chunk(ck.cbor_encode({"chunk_id": "c", "start_idx": 0, "end_idx": 0, "vectors": {}}))[3] == []
+    with pytest.raises(ck.PersistenceError):
+        ck.read_chunk(ck.cbor_encode({"chunk_id": "c", "start_idx": 0, "vectors": {}}))
+    with pytest.raises(ck.PersistenceError):
+        ck.read_chunk(ck.cbor_encode({"chunk_id": "c", "start_idx": 0, "end_idx": 0,
+                                      "vectors": ck.PairMap([([1, 2, 3], rows[0])])}))
+    with pytest.raises(ck.PersistenceError):
+        ck.read_chunk(b"\xa4\x68chunk")
+
+
+def test_manifest_rules():
+    # tests/integration/manifest_version_tests.rs: :52-107 future versions rejected, :109-136 version 1 accepted,
+    # :138-205 version / chunks / chunk_size are required
+    ok = {"version": 3, "chunk_size": 10000, "total_vectors": 0, "chunks": []}
+    m = ck.manifest_from_json(json.dumps(ok))
+    assert m["hnsw_structure"] is None and m["ivf_structure"] is None and m["deleted_vectors"] is None
+    for v in (1, 2, 3):
+        assert ck.manifest_from_json(json.dumps(dict(ok, version=v)))["version"] == v
+    for v in (4, 100):
+        with pytest.raises(ck.PersistenceError) as e:
+            ck.manifest_from_json(json.dumps(dict(ok, version=v)))
+        assert e.value.kind == "IncompatibleVersion"
+    for missing in ("version", "chunks", "chunk_size", "total_vectors"):
+        bad = dict(ok)
+        del bad[missing]
+        with pytest.raises(ck.PersistenceError):
+            ck.manifest_from_json(json.dumps(bad))
+    with pytest.raises(ck.PersistenceError):
+        ck.manifest_from_json("{ this is not json")  # tests/integration/chunked_load_tests.rs:261-275
+    dup = dict(ok, chunks=[{"chunk_id": "chunk-0", "cid": None, "vector_count": 1, "byte_size": 1,
+                            "vector_id_range": [[0] * 32, [0] * 32]}] * 2)
+    with pytest.raises(ck.PersistenceError) as e:
+        ck.manifest_validate(ck.manifest_from_json(json.dumps(dup)))
+    assert e.value.kind == "ChunkOverlap"
+
+
+def test_timestamps():
+    assert ck.parse_timestamp("1970-01-01T00:00:00Z") == 0.0
+    assert ck.parse_timestamp("2025-11-28T10:20:30.250Z") == ck.parse_timestamp("2025-11-28T10:20:30Z") + 0.25
+    assert ck.parse_timestamp("2025-11-28T11:20:30+01:00") == ck.parse_timestamp("2025-11-28T10:20:30Z")
+    assert ck.format_timestamp(0.0) == "1970-01-01T00:00:00Z" and ck.format_timestamp(1.5) == "1970-01-01T00:00:01.500Z"
+    for t in (0.0, 1764325230.0, 1764325230.125, 86400.0 * 20000 + 0.000001):
+        assert abs(ck.parse_timestamp(ck.format_timestamp(t)) - t) < 1e-6
+    with pytest.raises(ck.PersistenceError):
+        ck.parse_timestamp("yesterday")
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ctx():
+    c = fv.Context(0)
+    yield c
+    c.close()
+
+
+def build_index(ctx, n, d=16, nlist=8, seed=5, now=1000 * DAY):
+    x = mixture(n, d, n_comp=8, seed=seed)
+    kw = dict(max_connections=8, max_connections_layer_0=16, ef_construction=40, n_clusters=nlist, n_probe=4)
+    g = fv.HybridIndex(ctx, **kw)
+    g.set_ivf_centroids(x[:nlist].copy())
+    ids = {}
+    for i in range(n):
+        v = fv.VectorId(f"doc-{i}")
+        ids[v.row_id()] = v.bytes
+        g.insert_with_timestamp(v.row_id(), x[i], now - (1 if i % 3 else 30) * DAY - i, now)
+    return g, x, ids, kw
+
+
+@pytest.mark.gpu
+def test_save_layout_and_manifest(ctx):
+    # tests/integration/chunked_save_tests.rs: :101-131 empty index -> manifest only; :237-258 chunk_size+1 vectors ->
+    # two chunks; :260-293 chunk metadata; :340-394 hnsw / ivf structure present; :414-432 storage paths
+    st = ck.MemoryStorage()
+    m = ck.save_index_chunked(fv.HybridIndex(ctx), st, "test/empty")
+    assert list(st) == ["test/empty/manifest.json"] and m["total_vectors"] == 0 and m["version"] == 3
+    assert ck.load_index_chunked(ctx, st, "test/empty")[0].recent_count() == 0
+    with pytest.raises(ck.PersistenceError):
+        ck.save_index_chunked(fv.HybridIndex(ctx), st, "")
+    g, x, ids, kw = build_index(ctx, 101)
+    st = ck.MemoryStorage()
+    m = ck.save_index_chunked(g, st, "idx", id_table=ids, chunk_size=100)
+    assert sorted(st) == ["idx/chunks/chunk-0.cbor", "idx/chunks/chunk-1.cbor", "idx/hnsw_nodes.cbor", "idx/manifest.json",
+                          "idx/metadata.cbor", "idx/timestamps.cbor"]
+    assert [c["chunk_id"] for c in m["chunks"]] == ["chunk-0", "chunk-1"]
+    assert [c["vector_count"] for c in m["chunks"]] == [100, 1] and m["total_vectors"] == 101 and m["chunk_size"] == 100
+    assert all(c["byte_size"] == len(st[f"idx/chunks/{c['chunk_id']}.cbor"]) for c in m["chunks"])
+    assert all(len(c["vector_id_range"]) == 2 and len(c["vector_id_range"][0]) == 32 for c in m["chunks"])
+    on_disk = ck.manifest_from_json(st["idx/manifest.json"].decode())
+    ck.manifest_validate(on_disk)
+    assert on_disk == ck.manifest_from_json(json.dumps(m))
+    assert len(on_disk["hnsw_structure"]["node_chunk_map"]) == g.recent_count()
+    assert len(on_disk["ivf_structure"]["centroids"]) == 8 and len(on_disk["ivf_structure"]["centroids"][0]) == 16
+    assert sum(on_disk["hnsw_structure"]["layers"][0].values()) - 0 == g.recent_count()  # layer 0 holds every node
+    meta = ck.cbor_decode(st["idx/metadata.cbor"])
+    assert meta["recent_count"] == g.recent_count() and meta["historical_count"] == g.historical_count()
+    assert meta["config"]["recent_threshold"] == 7 * 86400 and meta["config"]["ivf_config"]["n_clusters"] == 8
+    assert meta["ivf_trained"] is True and meta["version"] == 1
+
+
+@pytest.mark.gpu
+def test_load_reproduces_the_saved_index(ctx, tmp_path):
+    # tests/integration/chunked_load_tests.rs: :137-151 counts, :183-214 both structures, :221-247 search after load
+    now = 1000 * DAY
+    g, x, ids, kw = build_index(ctx, 700, now=now)
+    dead_recent, dead_hist = fv.VectorId("doc-1").row_id(), fv.VectorId("doc-0").row_id()
+    g.delete(dead_recent, now)
+    g.delete(dead_hist, now)
+    ck.save_index_chunked(g, str(tmp_path), "idx", id_table=ids, now=now, chunk_size=256)
+    h, table = ck.load_index_chunked(ctx, str(tmp_path), "idx", now=now, **kw)
+    assert (h.recent_count(), h.historical_count()) == (g.recent_count(), g.historical_count())
+    assert h.is_initialized() and h.is_ivf_trained()
+    assert table == ids
+    # the graph is the saved graph, link for link; the lists hold the same rows (their order follows the chunks)
+    ga, ha = g.hnsw().export_graph(), h.hnsw().export_graph()
+    assert all(np.array_equal(a, b) for a, b in zip(ga, ha)) and g.hnsw().entry_point() == h.hnsw().entry_point()
+    assert h.hnsw().is_deleted(dead_recent)
+    for c in range(kw["n_clusters"]):
+        (gr, gi, _), (hr, hi, _) = g.ivf().export_list(c), h.ivf().export_list(c)
+        og, oh = np.argsort(gi), np.argsort(hi)
+        assert np.array_equal(gi[og], hi[oh]) and np.array_equal(bits(gr[og]), bits(hr[oh]))
+    ti, tt = g.export_timestamps()
+    ui, ut = h.export_timestamps()
+    assert np.array_equal(ti, ui) and np.allclose(tt, ut, atol=1e-5, rtol=0)
+    # searches agree: same ids, bit-identical distances (mixture data has no ties).  The row deleted from the graph
+    # stays deleted; the one deleted from a list comes back, as in the reference, whose load hashes the saved
+    # display strings again and so never finds them (src/hybrid/persistence.rs:675-682)
+    q = mixture(40, 16, n_comp=8, seed=77)
+    a = g.search(q, 10, now=now, hnsw_ef=40, ivf_n_probe=8)
+    b = h.search(q, 10, now=now, hnsw_ef=40, ivf_n_probe=8, search_historical=False)
+    a_recent = g.search(q, 10, now=now, hnsw_ef=40, ivf_n_probe=8, search_historical=False)
+    assert np.array_equal(a_recent.ids, b.ids) and np.array_equal(bits(a_recent.distances), bits(b.distances))
+    g2, _ = ck.load_index_chunked(ctx, str(tmp_path), "idx", now=now, **kw)
+    c = g2.search(q, 10, now=now, hnsw_ef=40, ivf_n_probe=8)
+    b = h.search(q, 10, now=now, hnsw_ef=40, ivf_n_probe=8)
+    assert np.array_equal(b.ids, c.ids) and np.array_equal(bits(b.distances), bits(c.distances))  # load is deterministic
+    compared = 0
+    for r in range(40):
+        if dead_hist in b.ids[r, :b.counts[r]]:
+            continue
+        compared += 1
+        assert a.counts[r] == b.counts[r] and np.array_equal(a.ids[r], b.ids[r])
+        assert np.array_equal(bits(a.distances[r]), bits(b.distances[r]))
+    assert compared >= 30
+    own = h.search(x[:1], 3, now=now, search_recent=False, ivf_n_probe=8)
+    assert own.ids[0, 0] == dead_hist and own.distances[0, 0] == 0.0
+    assert dead_hist not in g.search(x[:1], 3, now=now, search_recent=False, ivf_n_probe=8).ids[0]
+    # migration still works on the loaded index: the recent rows become due and are copied into the lists
+    assert h.migrate_with_threshold(0.5 * DAY, now) == g.migrate_with_threshold(0.5 * DAY, now) > 0
+
+
+@pytest.mark.gpu
+def test_load_errors(ctx):
+    # tests/integration/chunked_load_tests.rs:250-299
+    st = ck.MemoryStorage()
+    with pytest.raises(ck.PersistenceError) as e:
+        ck.load_index_chunked(ctx, st, "nowhere")
+    assert e.value.kind == "MissingComponent"
+    st.put("bad/manifest.json", b"{ this is not valid json }")
+    with pytest.raises(ck.PersistenceError):
+        ck.load_index_chunked(ctx, st, "bad")
+    st.put("future/manifest.json", json.dumps({"version": 99, "chunk_size": 10000, "total_vectors": 0, "chunks": []}).encode())
+    with pytest.raises(ck.PersistenceError) as e:
+        ck.load_index_chunked(ctx, st, "future")
+    assert e.value.kind == "IncompatibleVersion"
+    g, x, ids, kw = build_index(ctx, 50)
+    ck.save_index_chunked(g, st, "idx", id_table=ids)
+    for victim in ("idx/metadata.cbor", "idx/chunks/chunk-0.cbor", "idx/timestamps.cbor"):
+        st2 = ck.MemoryStorage(st)
+        del st2[victim]
+        with pytest.raises(ck.PersistenceError) as e:
+            ck.load_index_chunked(ctx, st2, "idx", **kw)
+        assert e.value.kind == "MissingComponent"
+    st2 = ck.MemoryStorage(st)
+    st2["idx/chunks/chunk-0.cbor"] = st2["idx/chunks/chunk-0.cbor"][:200]
+    with pytest.raises(ck.PersistenceError) as e:
+        ck.load_index_chunked(ctx, st2, "idx", **kw)
+    assert e.value.kind == "Deserialization"
+    with pytest.raises(ck.PersistenceError) as e:  # more clusters on disk than the caller's config has
+        ck.load_index_chunked(ctx, st, "idx", **dict(kw, n_clusters=4))
+    assert e.value.kind == "InvalidData"
