@@ -294,6 +294,19 @@ def cbor_decode(data):
     return v
 
 
+def plain(v):
+    """Decoded CBOR -> plain JSON-like Python values (serde_json::Value on the reference's side)."""
+    if isinstance(v, np.ndarray):
+        return [float(x) for x in v]
+    if isinstance(v, F32):
+        return float(v)
+    if isinstance(v, list):
+        return [plain(x) for x in v]
+    if isinstance(v, dict):
+        return {k: plain(x) for k, x in v.items()}
+    return v
+
+
 # ------------------------------------------------------------------------------------------------------
 # ids, timestamps
 # ------------------------------------------------------------------------------------------------------

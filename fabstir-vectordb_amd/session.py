@@ -128,8 +128,10 @@ class SessionError(Exception):
 class VectorDbSession:
     """bindings/node/src/session.rs VectorDBSession — search()/addVectors()/deleteVector() on the GPU index."""
 
-    def __init__(self, ctx, now=0.0, **hybrid_config):
+    def __init__(self, ctx, now=0.0, storage=None, session_id="session", **hybrid_config):
         self.ctx = ctx
+        self.storage = storage                              # get/put store (chunked.DirStorage / MemoryStorage)
+        self.session_id = session_id                        # path prefix of save_to_s5 (:636-642)
         self.index = HybridIndex(ctx, **hybrid_config)   # HybridConfig::default unless overridden
         self.vector_dimension = None                        # latched by the first addVectors (:345-357)
         self.metadata = {}                                  # VectorId string -> metadata (with _originalId)
@@ -222,6 +224,57 @@ class VectorDbSession:
             raise SessionError(f"Failed to delete vector: {e}") from e
 
     deleteVector = delete_vector
+
+    # -- save_to_s5 / load_user_vectors: session.rs:636-697, :99-198 ----------------------------------
+    def save_to_s5(self):
+        """Chunked index under `session_id/` plus `metadata_map.cbor`; returns the path identifier."""
+        from . import chunked
+        if self.destroyed:
+            raise SessionError("Session already destroyed")
+        if self.storage is None:
+            raise SessionError("Failed to save to S5: no storage configured")
+        ids = {rid: VectorId(md["_originalId"]).bytes for rid, key in self._rows.items()
+               for md in [self.metadata.get(key, {})] if isinstance(md.get("_originalId"), str)}
+        try:
+            chunked.save_index_chunked(self.index, self.storage, self.session_id, id_table=ids, now=self.now)
+        except chunked.PersistenceError as e:
+            raise SessionError(f"Failed to save index: {e}") from e
+        self.storage.put(f"{self.session_id}/metadata_map.cbor", chunked.cbor_encode(self.metadata))
+        return self.session_id
+
+    saveToS5 = save_to_s5
+
+    def load_user_vectors(self, cid, options=None):
+        """Replace the index with the one saved under `cid/` (HybridConfig::default, :118) and the metadata map with
+        `cid/metadata_map.cbor` (cleared when absent, :139-157)."""
+        from . import chunked
+        if self.destroyed:
+            raise SessionError("Session already destroyed")
+        if self.storage is None:
+            raise SessionError("Failed to load from S5: no storage configured")
+        try:
+            index, table = chunked.load_index_chunked(self.ctx, self.storage, cid, now=self.now)
+        except chunked.PersistenceError as e:
+            if e.kind == "MissingComponent":
+                raise SessionError(f"Missing index component: {e}") from e
+            if e.kind == "IncompatibleVersion":
+                raise SessionError(f"Incompatible index version: {e}") from e
+            raise SessionError(f"Failed to load index: {e}") from e
+        self.index = index
+        self._rows = {rid: chunked.display_id(b) for rid, b in table.items()}
+        data = self.storage.get(f"{cid}/metadata_map.cbor")
+        if data is None:
+            self.metadata = {}
+        else:
+            try:
+                md = chunked.cbor_decode(data)
+            except ValueError as e:
+                raise SessionError(f"Failed to deserialize metadata: {e}") from e
+            if not isinstance(md, dict):
+                raise SessionError("Failed to deserialize metadata: expected a map")
+            self.metadata = chunked.plain(md)
+
+    loadUserVectors = load_user_vectors
 
     def get_stats(self):
         return {"vector_count": self.index.recent_count() + self.index.historical_count(),

@@ -270,3 +270,33 @@ def test_load_errors(ctx):
     with pytest.raises(ck.PersistenceError) as e:  # more clusters on disk than the caller's config has
         ck.load_index_chunked(ctx, st, "idx", **dict(kw, n_clusters=4))
     assert e.value.kind == "InvalidData"
+
+
+@pytest.mark.gpu
+def test_session_save_to_s5_and_load_user_vectors(ctx):
+    # bindings/node/src/session.rs:636-697 saveToS5 (chunked index + metadata_map.cbor), :99-198 loadUserVectors
+    # (index replaced, metadata replaced or cleared), bindings/node/test/session.test.js save/load round trip
+    st = ck.MemoryStorage()
+    s = fv.VectorDbSession(ctx, storage=st, session_id="user-1")
+    docs = [{"id": f"doc-{i}", "vector": [float(i), 1.0, 0.5 * i, -2.0], "metadata": {"n": i, "tag": "even" if i % 2 == 0 else "odd",
+                                                                                    "w": 0.1 * i, "nested": {"a": [1, "x", None]}}}
+            for i in range(25)]
+    s.add_vectors(docs)
+    s.delete_vector("doc-3")
+    before = s.search([4.2, 1.0, 2.0, -2.0], 6)
+    assert s.save_to_s5() == "user-1"
+    assert {"user-1/manifest.json", "user-1/metadata_map.cbor", "user-1/chunks/chunk-0.cbor", "user-1/hnsw_nodes.cbor"} <= set(st)
+    t = fv.VectorDbSession(ctx, storage=st, session_id="user-2")
+    t.add_vectors([{"id": "old", "vector": [0.0, 0.0, 0.0, 0.0], "metadata": {"gone": True}}])
+    t.load_user_vectors("user-1")
+    assert t.get_stats() == s.get_stats() and "vec_" + fv.blake3(b"old")[:4].hex() not in t.metadata
+    after = t.search([4.2, 1.0, 2.0, -2.0], 6)
+    assert after == before and all(r["id"] != "doc-3" for r in after)
+    assert after[0]["id"] == "doc-4" and after[0]["metadata"] == docs[4]["metadata"]   # floats, nesting, null survive
+    flt = t.search([4.2, 1.0, 2.0, -2.0], 4, {"filter": {"tag": "odd"}})
+    assert flt == s.search([4.2, 1.0, 2.0, -2.0], 4, {"filter": {"tag": "odd"}}) and all(r["metadata"]["tag"] == "odd" for r in flt)
+    with pytest.raises(fv.session.SessionError):
+        t.load_user_vectors("nobody")
+    del st["user-1/metadata_map.cbor"]  # old format: metadata cleared, search still answers with display ids
+    t.load_user_vectors("user-1")
+    assert t.metadata == {} and t.search([4.2, 1.0, 2.0, -2.0], 1)[0]["id"].startswith("vec_")
