@@ -152,6 +152,7 @@ class _Dec:
         self.b = bytes(data)
         self.u8 = np.frombuffer(self.b, np.uint8)
         self.p = 0
+        self.depth = 0
 
     def _need(self, n):
         if self.p + n > len(self.b):
@@ -205,6 +206,15 @@ class _Dec:
         return out
 
     def item(self):
+        self.depth += 1
+        if self.depth > 128:  # serde_cbor's recursion limit
+            raise ValueError("CBOR nesting deeper than 128")
+        try:
+            return self._item()
+        finally:
+            self.depth -= 1
+
+    def _item(self):
         self._need(1)
         ib = self.b[self.p]
         self.p += 1
@@ -287,8 +297,12 @@ class _Dec:
 
 
 def cbor_decode(data):
+    """One CBOR item from `data`; anything malformed raises ValueError."""
     d = _Dec(data)
-    v = d.item()
+    try:
+        v = d.item()
+    except (IndexError, struct.error, UnicodeDecodeError, OverflowError, MemoryError, AttributeError, TypeError) as e:
+        raise ValueError(f"malformed CBOR: {e}") from e
     if d.p != len(d.b):
         raise ValueError("trailing bytes after the CBOR item")  # serde_cbor::from_slice rejects them too
     return v
@@ -653,6 +667,8 @@ def load_index_chunked(ctx, storage, path, now=0.0, **config):
                     if l < len(layers):
                         flat += [x for x in layers[l] if x in known]  # a link to a missing node is never followed
                     off.append(len(flat))
+            if any(v.size != nvec[0].size or v.size == 0 for v in nvec):
+                raise PersistenceError("HNSWError", "Failed to restore node: vectors of different dimensions")
             try:
                 index.hnsw().restore(np.asarray(nid, np.uint64), np.stack(nvec), np.asarray(nlev, np.uint32),
                                      np.asarray(off, np.uint64), np.asarray(flat, np.uint64), entry)
@@ -682,6 +698,11 @@ def load_index_chunked(ctx, storage, path, now=0.0, **config):
         if keep and clusters:
             if not cents:
                 raise PersistenceError("IVFError", "Failed to find cluster: index not trained")
+            dim = len(cents[0])
+            for i in keep:  # find_cluster's dimension check (src/ivf/core.rs:493-507)
+                if all_rows[i].size != dim:
+                    raise PersistenceError("IVFError", f"Failed to find cluster: Dimension mismatch: expected {dim}, "
+                                                       f"got {all_rows[i].size}")
             x = np.stack([all_rows[i] for i in keep])
             rid = np.asarray([row_id(all_ids[i]) for i in keep], np.uint64)
             ivf = index.ivf()

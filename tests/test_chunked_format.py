@@ -57,6 +57,39 @@ def test_cbor_rfc8949_appendix_a():
             ck.cbor_decode(bytes.fromhex(bad))
 
 
+def test_cbor_decoder_rejects_damage_cleanly():
+    # a damaged file must come out as a Deserialization error, never as a crash or a hang
+    from hypothesis import given, settings, strategies as hs
+    good = ck.cbor_encode({"chunk_id": "chunk-0", "start_idx": 0, "end_idx": 1, "vectors": ck.PairMap(
+        [(ck.VectorIdBytes(fv.blake3(b"a")), np.asarray([0.25, 1e-3, 3.0], np.float32)),
+         (ck.VectorIdBytes(fv.blake3(b"b")), np.asarray([1.0, 2.0, 7.7], np.float32))])})
+
+    def run(data):
+        try:
+            ck.read_chunk(data)
+        except ck.PersistenceError as e:
+            assert e.kind == "Deserialization"
+
+    @settings(max_examples=300, deadline=None)
+    @given(hs.binary(max_size=64))
+    def random_bytes(data):
+        run(data)
+
+    @settings(max_examples=300, deadline=None)
+    @given(hs.integers(0, len(good) - 1), hs.integers(0, 255), hs.integers(0, len(good)))
+    def one_byte_changed_and_truncated(pos, val, cut):
+        b = bytearray(good)
+        b[pos] = val
+        run(bytes(b))
+        run(good[:cut])
+
+    random_bytes()
+    one_byte_changed_and_truncated()
+    for hexed in ("81" * 200 + "00", "9b7fffffffffffffff", "bb7fffffffffffffff", "5b7fffffffffffffff", "7f", "9f", "bf00"):
+        with pytest.raises(ValueError):
+            ck.cbor_decode(bytes.fromhex(hexed))
+
+
 def test_f32_arrays_take_the_shortest_exact_form():
     rng = np.random.default_rng(1)
     a = rng.standard_normal(1000).astype(np.float32)
