@@ -456,9 +456,8 @@ def manifest_validate(m):
 # ------------------------------------------------------------------------------------------------------
 # save_index_chunked (persistence.rs:188-277)
 # ------------------------------------------------------------------------------------------------------
-def _config_of(index):
+def _config_of(c):
     """HybridConfig as serde writes it (src/hybrid/core.rs:37-46, Duration as whole seconds :49-67)."""
-    c = index.config
     return {"recent_threshold": int(c["recent_threshold"]),
             "hnsw_config": {"max_connections": c["max_connections"], "max_connections_layer_0": c["max_connections_layer_0"],
                             "ef_construction": c["ef_construction"], "seed": c.get("hnsw_seed")},
@@ -468,37 +467,60 @@ def _config_of(index):
             "min_ivf_training_size": c["min_ivf_training_size"]}
 
 
+def snapshot_of(index):
+    """Everything save_index_chunked writes, copied out of a HybridIndex (lists come back from HBM in list order)."""
+    hnsw, ivf = index.hnsw(), index.ivf()
+    nids, nlev, noff, nnb = hnsw.export_graph()
+    trained = ivf.is_trained()
+    tids, ts = index.export_timestamps()
+    return {"config": dict(index.config), "recent_count": index.recent_count(), "historical_count": index.historical_count(),
+            "ivf_trained": index.is_ivf_trained(),
+            "node_ids": nids, "node_levels": nlev, "node_offsets": noff, "node_neighbors": nnb,
+            "node_vectors": [hnsw.get_vector_by_id(i) for i in nids.tolist()],
+            "node_deleted": [hnsw.is_deleted(i) for i in nids.tolist()], "entry_point": hnsw.entry_point(),
+            "centroids": ivf.get_centroids() if trained else None,
+            "lists": [ivf.export_list(c) for c in range(index.n_clusters)] if trained else [],
+            "timestamp_ids": tids, "timestamps": ts}
+
+
 def save_index_chunked(index, storage, path, id_table=None, now=0.0, chunk_size=CHUNK_SIZE):
     """Write `index` (a HybridIndex) under `path` in the reference's chunked layout; returns the manifest dict.
     `id_table`: u64 row id -> 32-byte VectorId (rows not in it get default_id_bytes)."""
+    if not path:
+        raise PersistenceError("InvalidData", "Path cannot be empty")
+    return write_snapshot(snapshot_of(index), storage, path, id_table, now, chunk_size)
+
+
+def write_snapshot(snap, storage, path, id_table=None, now=0.0, chunk_size=CHUNK_SIZE):
+    """save_index_chunked's steps 1-9 over a snapshot (see snapshot_of for the fields)."""
     if not path:
         raise PersistenceError("InvalidData", "Path cannot be empty")
     if isinstance(storage, str):
         storage = DirStorage(storage)
     id_table = id_table or {}
     vid = lambda r: VectorIdBytes(id_table.get(int(r)) or default_id_bytes(r))  # noqa: E731
-    total = index.recent_count() + index.historical_count()
+    total = snap["recent_count"] + snap["historical_count"]
     manifest = {"version": MANIFEST_VERSION, "chunk_size": chunk_size, "total_vectors": total, "chunks": [],
                 "hnsw_structure": None, "ivf_structure": None}
     if total == 0:
         storage.put(f"{path}/manifest.json", json.dumps(manifest, indent=2).encode())
         return manifest
-    hnsw, ivf = index.hnsw(), index.ivf()
     # 1. every vector: live graph nodes, then every row of every inverted list (:279-311)
-    nids, nlev, noff, nnb = hnsw.export_graph()
-    nvec = [hnsw.get_vector_by_id(i) for i in nids.tolist()]
-    ndel = [hnsw.is_deleted(i) for i in nids.tolist()]
+    nids, nlev = np.asarray(snap["node_ids"], np.uint64), np.asarray(snap["node_levels"], np.uint32)
+    noff, nnb = np.asarray(snap["node_offsets"], np.uint64), np.asarray(snap["node_neighbors"], np.uint64)
+    nvec, ndel = snap["node_vectors"], [bool(x) for x in snap["node_deleted"]]
     all_ids = [i for i, dead in zip(nids.tolist(), ndel) if not dead]
     all_vecs = [v for v, dead in zip(nvec, ndel) if not dead]
+    trained = snap["centroids"] is not None
+    n_clusters = snap["config"]["n_clusters"]
     ivf_deleted, nonempty = [], []
-    if ivf.is_trained():
-        for c in range(index.n_clusters):
-            rows, ids, live = ivf.export_list(c)
-            if ids.size:
-                nonempty.append(c)
-            all_ids += ids.tolist()
-            all_vecs += list(rows)
-            ivf_deleted += ids[~live].tolist()
+    for c, (rows, ids, live) in enumerate(snap["lists"]):
+        ids, live = np.asarray(ids, np.uint64), np.asarray(live, bool)
+        if ids.size:
+            nonempty.append(c)
+        all_ids += ids.tolist()
+        all_vecs += list(rows)
+        ivf_deleted += ids[~live].tolist()
     # 2-3. chunks of `chunk_size` in that order (:313-338), one CBOR file each (:340-375)
     n_chunks = 0
     for s in range(0, len(all_ids), chunk_size):
@@ -514,26 +536,24 @@ def save_index_chunked(index, storage, path, id_table=None, now=0.0, chunk_size=
     # the reference's placeholder node -> chunk rule (:455-475): chunk (len("vec_xxxxxxxx") mod n_chunks)
     chunk_of = manifest["chunks"][12 % n_chunks]["chunk_id"] if n_chunks else "chunk-0"
     # 4. graph summary (:377-405)
-    entry = hnsw.entry_point()
+    entry = snap["entry_point"]
     layers = [int(np.sum(nlev >= l)) for l in range(int(nlev.max()) + 1)] if nids.size else [0]
     manifest["hnsw_structure"] = {
         "entry_point": list(vid(entry) if entry is not None else VectorIdBytes(blake3(b"placeholder"))),
         "layers": [{"layer_id": l, "node_count": c} for l, c in enumerate(layers)],
         "node_chunk_map": {display_id(vid(r)): chunk_of for r in nids.tolist()}}
     # 5. centroids + which chunks hold each cluster's rows (:407-453)
-    cents = ivf.get_centroids() if ivf.is_trained() else np.zeros((0, 0), np.float32)
     manifest["ivf_structure"] = {
-        "centroids": [[float(x) for x in row] for row in cents],
-        "cluster_assignments": {str(c): ([chunk_of] if c in nonempty else []) for c in range(index.n_clusters)}
-        if ivf.is_trained() else {}}
+        "centroids": [[float(x) for x in row] for row in snap["centroids"]] if trained else [],
+        "cluster_assignments": {str(c): ([chunk_of] if c in nonempty else []) for c in range(n_clusters)} if trained else {}}
     deleted = [display_id(vid(r)) for r, dead in zip(nids.tolist(), ndel) if dead] + [display_id(vid(r)) for r in ivf_deleted]
     if deleted:
         manifest["deleted_vectors"] = deleted
     storage.put(f"{path}/manifest.json", json.dumps(manifest, indent=2).encode())
     # 7. timestamps
-    tids, ts = index.export_timestamps()
-    storage.put(f"{path}/timestamps.cbor", cbor_encode(
-        {"timestamps": PairMap([(vid(r), format_timestamp(t)) for r, t in zip(tids.tolist(), ts.tolist())])}))
+    storage.put(f"{path}/timestamps.cbor", cbor_encode({"timestamps": PairMap(
+        [(vid(r), format_timestamp(t)) for r, t in zip(np.asarray(snap["timestamp_ids"]).tolist(),
+                                                       np.asarray(snap["timestamps"]).tolist())])}))
     # 8. every node with its links, deleted ones too
     nodes, slot = [], 0
     for i, r in enumerate(nids.tolist()):
@@ -542,13 +562,13 @@ def save_index_chunked(index, storage, path, id_table=None, now=0.0, chunk_size=
             nb.append([vid(x) for x in nnb[int(noff[slot]):int(noff[slot + 1])].tolist()])
             slot += 1
         nodes.append({"id": vid(r), "vector": np.asarray(nvec[i], np.float32), "level": int(nlev[i]), "neighbors": nb,
-                      "is_deleted": bool(ndel[i])})
+                      "is_deleted": ndel[i]})
     storage.put(f"{path}/hnsw_nodes.cbor", cbor_encode(nodes))
     # 9. metadata
     storage.put(f"{path}/metadata.cbor", cbor_encode(
-        {"version": METADATA_VERSION, "config": _config_of(index), "recent_count": index.recent_count(),
-         "historical_count": index.historical_count(), "total_vectors": total, "timestamp": format_timestamp(now),
-         "ivf_trained": index.is_ivf_trained()}))
+        {"version": METADATA_VERSION, "config": _config_of(snap["config"]), "recent_count": snap["recent_count"],
+         "historical_count": snap["historical_count"], "total_vectors": total, "timestamp": format_timestamp(now),
+         "ivf_trained": bool(snap["ivf_trained"])}))
     return manifest
 
 

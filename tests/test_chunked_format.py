@@ -333,3 +333,64 @@ def test_session_save_to_s5_and_load_user_vectors(ctx):
     del st["user-1/metadata_map.cbor"]  # old format: metadata cleared, search still answers with display ids
     t.load_user_vectors("user-1")
     assert t.metadata == {} and t.search([4.2, 1.0, 2.0, -2.0], 1)[0]["id"].startswith("vec_")
+
+
+# ---- frozen fixture: tests/golden/chunked_small (made by tests/golden/make_chunked_golden.py) --------------------
+import os  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chunked_small")
+
+
+def test_golden_chunked_files_decode_to_the_recorded_state():
+    f = np.load(os.path.join(GOLD, "expected.npz"))
+    st = ck.DirStorage(GOLD)
+    m = ck.manifest_from_json(st.get("idx/manifest.json").decode())
+    ck.manifest_validate(m)
+    assert m["version"] == 3 and m["chunk_size"] == 100 and [c["vector_count"] for c in m["chunks"]] == [100, 100, 39]
+    by_id = {bytes(b): i for i, b in enumerate(f["id_bytes"])}
+    seen = []
+    for c in m["chunks"]:
+        data = st.get(f"idx/chunks/{c['chunk_id']}.cbor")
+        assert len(data) == c["byte_size"]
+        cid, s, e, ids, rows = ck.read_chunk(data)
+        assert cid == c["chunk_id"] and s == len(seen) and e == min(s + 99, 238) and len(ids) == c["vector_count"]
+        assert c["vector_id_range"] == [list(ids[0]), list(ids[-1])]
+        for b, r in zip(ids, rows):
+            assert np.array_equal(bits(r), bits(f["x"][by_id[b]]))
+        seen += ids
+    # every vector once, except the deleted graph node (collect_all_vectors skips it, persistence.rs:289-293)
+    assert len(seen) == len(set(seen)) == 239 and bytes(f["id_bytes"][int(f["dead_recent"])]) not in seen
+    nodes = ck.cbor_decode(st.get("idx/hnsw_nodes.cbor"))
+    assert [ck.row_id(bytes(n["id"])) for n in nodes] == f["node_ids"].tolist()
+    assert [n["level"] for n in nodes] == f["node_levels"].tolist()
+    flat = [ck.row_id(bytes(x)) for n in nodes for layer in n["neighbors"] for x in layer]
+    assert flat == f["node_neighbors"].tolist() and sum(n["is_deleted"] for n in nodes) == 1
+    ts = ck.cbor_decode(st.get("idx/timestamps.cbor"))["timestamps"].pairs
+    assert [ck.row_id(bytes(k)) for k, _ in ts] == f["row_ids"].tolist()
+    assert np.allclose([ck.parse_timestamp(v) for _, v in ts], f["timestamps"], rtol=0, atol=1e-6)
+    assert set(m["hnsw_structure"]["node_chunk_map"]) == {ck.display_id(bytes(n["id"])) for n in nodes}
+    assert m["deleted_vectors"] == [ck.display_id(bytes(f["id_bytes"][int(f[k])])) for k in ("dead_recent", "dead_hist")]
+    # the writer still produces these bytes
+    again = ck.cbor_encode({"chunk_id": "chunk-2", "start_idx": 200, "end_idx": 238, "vectors": ck.PairMap(
+        [(ck.VectorIdBytes(b), f["x"][by_id[b]]) for b in seen[200:]])})
+    assert again == st.get("idx/chunks/chunk-2.cbor")
+
+
+@pytest.mark.gpu
+def test_golden_chunked_index_opens_to_the_oracles_answers(ctx):
+    f = np.load(os.path.join(GOLD, "expected.npz"))
+    kw = dict(max_connections=6, max_connections_layer_0=12, ef_construction=30, n_clusters=5, n_probe=3)
+    now = float(f["now"])
+    h, table = ck.load_index_chunked(ctx, GOLD, "idx", now=now, **kw)
+    assert table == {int(r): bytes(b) for r, b in zip(f["row_ids"], f["id_bytes"])}
+    assert h.recent_count() + h.historical_count() == 240 and h.is_ivf_trained()
+    assert [h.ivf().get_cluster_size(c) for c in range(5)] == f["list_sizes"].tolist()
+    got = h.search(f["queries"], int(f["k"]), now=now, hnsw_ef=int(f["ef"]), ivf_n_probe=int(f["nprobe"]))
+    assert np.array_equal(got.counts, f["out_counts"])
+    for b in range(len(got)):
+        n = int(got.counts[b])
+        assert np.array_equal(got.ids[b, :n], f["out_ids"][b, :n]), f"query {b}"
+        assert np.array_equal(bits(got.distances[b, :n]), bits(f["out_dist"][b, :n])), f"query {b}"
+    # the duplicate pair: rows 16 and 17 are the same vector in one list; list position decides, and it survived
+    dup = h.search(f["x"][16:17], 2, now=now, search_recent=False, ivf_n_probe=5)
+    assert dup.ids[0].tolist() == [int(f["row_ids"][16]), int(f["row_ids"][17])] and np.all(dup.distances[0] == 0.0)
