@@ -218,12 +218,56 @@ class VectorDbSession:
 
     def delete_vector(self, id):
         vid = VectorId(id)
+        if self.destroyed:
+            raise SessionError("Session already destroyed")
         try:
             self.index.delete(vid.row_id(), self.now)
         except Exception as e:
             raise SessionError(f"Failed to delete vector: {e}") from e
+        self.metadata.pop(vid.to_string(), None)  # :464-467
 
     deleteVector = delete_vector
+
+    # -- delete_by_metadata: session.rs:489-578 ----------------------------------------------------
+    def delete_by_metadata(self, flt):
+        """Soft-delete every vector whose metadata matches the simple field filter (`matches_filter` below).
+        Returns {"deleted_count", "deleted_ids"} with the user's original ids."""
+        if self.destroyed:
+            raise SessionError("Session already destroyed")
+        matching = []
+        for key, md in self.metadata.items():
+            if matches_filter(md, flt):
+                oid = md.get("_originalId") if isinstance(md, dict) else None
+                matching.append((key, oid if isinstance(oid, str) else key))
+        ok = 0
+        for _, oid in matching:  # batch_delete (src/hybrid/core.rs:968-986): failures are counted, not raised
+            try:
+                self.index.delete(VectorId(oid).row_id(), self.now)
+                ok += 1
+            except Exception:  # noqa: BLE001
+                pass
+        done = matching[:ok]  # the first `successful` entries, as the reference takes them (:553-558)
+        for key, _ in done:
+            self.metadata.pop(key, None)
+        return {"deleted_count": ok, "deleted_ids": [oid for _, oid in done]}
+
+    deleteByMetadata = delete_by_metadata
+
+    # -- update_metadata: session.rs:581-632 -------------------------------------------------------
+    def update_metadata(self, id, metadata):
+        if self.destroyed:
+            raise SessionError("Session already destroyed")
+        key = VectorId(id).to_string()
+        if key not in self.metadata:
+            raise SessionError(f"Vector with id '{id}' does not exist")
+        if isinstance(metadata, dict):
+            md = dict(metadata)
+            md["_originalId"] = id
+        else:
+            md = {"_originalId": id, "_userMetadata": metadata}
+        self.metadata[key] = md
+
+    updateMetadata = update_metadata
 
     # -- save_to_s5 / load_user_vectors: session.rs:636-697, :99-198 ----------------------------------
     def save_to_s5(self):
@@ -277,12 +321,42 @@ class VectorDbSession:
     loadUserVectors = load_user_vectors
 
     def get_stats(self):
-        return {"vector_count": self.index.recent_count() + self.index.historical_count(),
-                "hnsw_vector_count": self.index.recent_count(), "ivf_vector_count": self.index.historical_count()}
+        # session.rs:699-722: vector_count is the ACTIVE count (soft-deleted rows excluded)
+        if self.destroyed:
+            raise SessionError("Session already destroyed")
+        hnsw, ivf = self.index.hnsw(), self.index.ivf()
+        hnsw_deleted = hnsw.node_count() - hnsw.active_count()
+        ivf_deleted = ivf.total_vectors() - ivf.active_count()
+        return {"vector_count": hnsw.active_count() + ivf.active_count(), "index_type": "hybrid",
+                "hnsw_vector_count": self.index.recent_count(), "ivf_vector_count": self.index.historical_count(),
+                "hnsw_deleted_count": hnsw_deleted, "ivf_deleted_count": ivf_deleted,
+                "total_deleted_count": hnsw_deleted + ivf_deleted}
 
     def destroy(self):
         self.destroyed = True
         self.index = None
+
+
+def matches_filter(metadata, flt):
+    """bindings/node/src/session.rs:831-889: every filter field must be present (dotted paths descend) and equal —
+    or, when the metadata value is an array, contain the filter value.  A non-object filter matches nothing, an
+    empty one everything."""
+    from .metadata_filter import json_eq
+    if not isinstance(flt, dict):
+        return False
+    for key, want in flt.items():
+        cur = metadata
+        for part in (key.split(".") if "." in key else [key]):
+            if isinstance(cur, dict) and part in cur:
+                cur = cur[part]
+            else:  # Value::get(&str) finds nothing in arrays and scalars
+                return False
+        if isinstance(cur, list):
+            if not any(json_eq(x, want) for x in cur):
+                return False
+        elif not json_eq(cur, want):
+            return False
+    return True
 
 
 def rest_search(index, request, id_of_row=None, now=0.0):

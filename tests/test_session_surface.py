@@ -68,3 +68,47 @@ def test_session_topk_and_scores():
     s.destroy()
     with pytest.raises(fv.session.SessionError):
         s.search([0.0, 1.0, 0.5], 1)
+
+
+def test_session_simple_filter_semantics():
+    # bindings/node/src/session.rs:831-889 (matches_filter / get_field_value / values_match)
+    mf = fv.session.matches_filter
+    md = {"category": "tech", "views": 10, "score": 1.5, "tags": ["ai", "ml"], "user": {"id": "123", "lvl": 2}, "n": None}
+    assert mf(md, {}) and not mf(md, "tech") and not mf(md, None) and not mf(md, ["category"])
+    assert mf(md, {"category": "tech"}) and not mf(md, {"category": "art"}) and not mf(md, {"missing": 1})
+    assert mf(md, {"category": "tech", "views": 10}) and not mf(md, {"category": "tech", "views": 11})   # AND
+    assert mf(md, {"user.id": "123"}) and not mf(md, {"user.id": 123}) and not mf(md, {"user.name": "x"})
+    assert mf(md, {"tags": "ai"}) and not mf(md, {"tags": "db"}) and not mf(md, {"tags": ["ai", "ml"]})  # membership
+    assert mf(md, {"views": 10}) and not mf(md, {"views": 10.0}) and mf(md, {"score": 1.5})             # Value equality
+    assert mf(md, {"n": None}) and not mf(md, {"tags.0": "ai"}) and mf(md, {"user": {"id": "123", "lvl": 2}})
+
+
+@pytest.mark.gpu
+def test_session_delete_by_metadata_update_metadata_and_stats():
+    # bindings/node/src/session.rs:447-632, :699-722; bindings/node/test (deleteByMetadata / updateMetadata suites)
+    ctx = fv.Context(0)
+    s = fv.VectorDbSession(ctx)
+    s.add_vectors([{"id": f"doc-{i}", "vector": [float(i), 1.0, 0.5], "metadata": {"n": i, "tag": ["even"] if i % 2 == 0 else ["odd"],
+                                                                                 "user": {"id": str(i % 3)}}} for i in range(12)])
+    st = s.get_stats()
+    assert st["vector_count"] == 12 and st["total_deleted_count"] == 0 and st["index_type"] == "hybrid"
+    r = s.delete_by_metadata({"tag": "odd", "user.id": "1"})      # doc-1, doc-7
+    assert r == {"deleted_count": 2, "deleted_ids": ["doc-1", "doc-7"]}
+    assert s.delete_by_metadata({"tag": "odd", "user.id": "1"}) == {"deleted_count": 0, "deleted_ids": []}
+    st = s.get_stats()
+    assert st["vector_count"] == 10 and st["hnsw_deleted_count"] + st["ivf_deleted_count"] == st["total_deleted_count"] == 2
+    assert st["hnsw_vector_count"] + st["ivf_vector_count"] == 12          # soft delete: the rows are still stored
+    assert all(x["id"] not in ("doc-1", "doc-7") for x in s.search([1.0, 1.0, 0.5], 12))
+    s.delete_vector("doc-0")
+    assert "vec_" + fv.blake3(b"doc-0")[:4].hex() not in s.metadata and s.get_stats()["vector_count"] == 9
+    s.update_metadata("doc-2", {"n": 200, "fresh": True})
+    top = s.search([2.0, 1.0, 0.5], 1)[0]
+    assert top["id"] == "doc-2" and top["metadata"] == {"n": 200, "fresh": True}
+    s.update_metadata("doc-4", "just a string")
+    assert s.search([4.0, 1.0, 0.5], 1)[0] == {"id": "doc-4", "score": 1.0, "metadata": "just a string"}
+    with pytest.raises(fv.session.SessionError):
+        s.update_metadata("doc-0", {"n": 1})    # deleted -> metadata gone -> "does not exist"
+    with pytest.raises(fv.session.SessionError):
+        s.update_metadata("never-added", {})
+    assert s.delete_by_metadata({}) ["deleted_count"] == 9        # an empty filter matches everything left
+    assert s.get_stats()["vector_count"] == 0 and s.search([4.0, 1.0, 0.5], 3) == []
