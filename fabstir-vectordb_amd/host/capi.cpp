@@ -225,6 +225,11 @@ int fvh_hybrid_from_parts(void* p, const uint64_t* ids, const double* ts, uint64
                           uint64_t historical_count, int ivf_trained) {
   return ((HybridIndex*)p)->from_parts(ids, ts, n, recent_count, historical_count, ivf_trained != 0);
 }
+int fvh_hybrid_vacuum(void* p, uint64_t* hnsw_removed, uint64_t* ivf_removed) {
+  return ((HybridIndex*)p)->vacuum(hnsw_removed, ivf_removed);
+}
+int fvh_ivf_vacuum(void* p, uint64_t* removed) { return ((IVFIndex*)p)->vacuum(removed); }
+uint64_t fvh_hnsw_vacuum(void* p) { return ((HNSWIndex*)p)->vacuum(); }
 uint64_t fvh_hybrid_timestamp_count(void* p) { return ((HybridIndex*)p)->timestamp_count(); }
 void fvh_hybrid_export_timestamps(void* p, uint64_t* ids, double* ts) { ((HybridIndex*)p)->export_timestamps(ids, ts); }
 uint64_t fvh_hybrid_recent_count(void* p) { return ((HybridIndex*)p)->recent_count(); }

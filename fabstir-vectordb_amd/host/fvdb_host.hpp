@@ -96,6 +96,8 @@ class IVFIndex {
   int mark_deleted(uint64_t id);                                                  // operations.rs:569
   bool is_deleted(uint64_t id) const { return deleted_.count(id) > 0; }
   uint64_t active_count() const { return total_ - deleted_.size(); }
+  uint64_t deleted_count() const { return deleted_.size(); }
+  int vacuum(uint64_t* removed);                                                  // operations.rs:625
   uint64_t cluster_size(uint32_t c) const;
   // list `c` in list-position order, copied back from HBM (save path, src/hybrid/persistence.rs:289-311)
   int export_list(uint32_t c, float* rows, uint64_t* ids, uint8_t* live) const;
@@ -152,6 +154,7 @@ class HNSWIndex {
   int mark_deleted(uint64_t id);                                                   // operations.rs:127
   bool is_deleted(uint64_t id) const;
   uint64_t active_count() const;
+  uint64_t vacuum();                                                               // operations.rs:176
   int64_t level_of(uint64_t id) const;
   int64_t neighbors(uint64_t id, uint32_t layer, uint64_t* out, uint64_t cap) const;
   const float* vector_of(uint64_t id) const;  // host copy (migration, get_vector_by_id)
@@ -254,7 +257,7 @@ class HNSWIndex {
   fvdb_scorer* scorer_ = nullptr;
   uint32_t scorer_B_ = 0, scorer_C_ = 0;
   uint32_t dim_ = 0;
-  bool has_dim_ = false, has_entry_ = false;
+  bool has_dim_ = false, has_entry_ = false, entry_lost_ = false;
   uint32_t entry_ = 0;
   uint64_t n_registered_ = 0;
   std::vector<uint64_t> ids_;
@@ -336,6 +339,8 @@ class HybridIndex {
   // table and counters; the index becomes initialised.  Only valid while the timestamp table is empty.
   int from_parts(const uint64_t* ids, const double* ts, uint64_t n, uint64_t recent_count, uint64_t historical_count,
                  bool ivf_trained);
+  // vacuum (src/hybrid/core.rs:989-1012): both indexes; refused while a batch is in flight
+  int vacuum(uint64_t* hnsw_removed, uint64_t* ivf_removed);
   uint64_t timestamp_count() const { return ts_order_.size(); }
   void export_timestamps(uint64_t* ids, double* ts) const;  // insertion order
   HNSWIndex& recent() { return *recent_; }

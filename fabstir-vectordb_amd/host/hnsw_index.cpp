@@ -634,6 +634,7 @@ int HNSWIndex::finish_failed(const float* q, bool q_on_device, uint32_t dim, uin
 bool HNSWIndex::search_dev_begin(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, int* rc,
                                  uint32_t slot) {
   *rc = FVDB_OK;
+  if (entry_lost_) return false;  // the caller's search_dev fallback reports the error
   if (!has_entry_ || B == 0 || k == 0 || (has_dim_ && dim != dim_) || !device_path_ok(ef)) return false;
   *rc = device_launch(q_dev, B, k, ef, slot);
   return *rc == FVDB_OK;
@@ -656,6 +657,7 @@ int HNSWIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint32_
   }
   if (!has_entry_) return FVDB_OK;  // empty index -> empty results (:404-407)
   if (has_dim_ && dim != dim_) return FVDB_E_DIM;
+  if (entry_lost_) return FVDB_E_NOT_FOUND;  // "Entry point node not found in index" (:422-429)
   if (B == 0 || k == 0) return FVDB_OK;
   if (!device_path_ok(ef)) return search_host_walk(q, q_on_device, B, k, ef, ids, dist, counts);
   const float* qd = q;
@@ -767,6 +769,7 @@ int HNSWIndex::score_pairs_from_row(uint32_t base_row, const std::vector<uint32_
 int HNSWIndex::insert(uint64_t id, const float* v, uint32_t dim, int64_t forced_level) {
   if (index_of_.count(id)) return FVDB_E_DUPLICATE;
   if (has_dim_ && dim != dim_) return FVDB_E_DIM;
+  if (entry_lost_) return FVDB_E_NOT_FOUND;  // the reference unwraps the missing entry node here (:268-274)
   if (!has_dim_) {
     dim_ = dim;
     has_dim_ = true;
@@ -893,9 +896,39 @@ int HNSWIndex::restore(const uint64_t* ids, const float* v, uint64_t n, uint32_t
   return FVDB_OK;
 }
 
+// src/hnsw/operations.rs:176-200: deleted nodes leave the node map and every neighbour set.  Their rows stay in HBM
+// unreferenced (the row store is append-only); `registered_ == 0` is this mirror's "nodes.get() == None".  The
+// reference does not repair an entry point that was removed: its searches then fail and its insert panics.
+uint64_t HNSWIndex::vacuum() {
+  std::vector<uint8_t> dead(ids_.size(), 0);
+  uint64_t removed = 0;
+  for (size_t i = 0; i < ids_.size(); ++i)
+    if (registered_[i] && deleted_[i]) {
+      dead[i] = 1;
+      ++removed;
+    }
+  if (removed == 0) return 0;
+  for (size_t i = 0; i < ids_.size(); ++i) {
+    if (dead[i]) {
+      registered_[i] = 0;
+      auto it = index_of_.find(ids_[i]);
+      if (it != index_of_.end() && it->second == i) index_of_.erase(it);
+      for (auto& l : nbrs_[i]) l.clear();
+    } else if (registered_[i]) {
+      for (auto& l : nbrs_[i])
+        l.erase(std::remove_if(l.begin(), l.end(), [&](uint32_t x) { return dead[x] != 0; }), l.end());
+    }
+  }
+  n_registered_ -= removed;
+  if (has_entry_ && dead[entry_]) entry_lost_ = true;
+  graph_dirty_ = true;
+  return removed;
+}
+
 uint64_t HNSWIndex::graph_slots() const {
   uint64_t s = 0;
-  for (size_t i = 0; i < ids_.size(); ++i) s += level_[i] + 1;
+  for (size_t i = 0; i < ids_.size(); ++i)
+    if (registered_[i]) s += level_[i] + 1;
   return s;
 }
 uint64_t HNSWIndex::graph_edges() const {
@@ -905,10 +938,11 @@ uint64_t HNSWIndex::graph_edges() const {
   return e;
 }
 void HNSWIndex::export_graph(uint64_t* ids, uint32_t* levels, uint64_t* nbr_offsets, uint64_t* nbrs) const {
-  uint64_t slot = 0, e = 0;
+  uint64_t slot = 0, e = 0, w = 0;
   for (size_t i = 0; i < ids_.size(); ++i) {
-    ids[i] = ids_[i];
-    levels[i] = level_[i];
+    if (!registered_[i]) continue;  // vacuumed
+    ids[w] = ids_[i];
+    levels[w++] = level_[i];
     for (uint32_t l = 0; l <= level_[i]; ++l, ++slot) {
       nbr_offsets[slot] = e;
       for (uint32_t x : nbrs_[i][l]) nbrs[e++] = ids_[x];

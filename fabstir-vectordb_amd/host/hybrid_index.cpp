@@ -184,7 +184,6 @@ int HybridIndex::bulk_insert_sharded(const uint64_t* ids, const float* v, uint64
   return FVDB_OK;
 }
 
-// src/hybrid/core.rs:600-649 — copies into IVF, never removes from HNSW (:577-581)
 // src/hybrid/core.rs:857-877
 int HybridIndex::from_parts(const uint64_t* ids, const double* ts, uint64_t n, uint64_t recent_count,
                             uint64_t historical_count, bool ivf_trained) {
@@ -207,6 +206,13 @@ int HybridIndex::from_parts(const uint64_t* ids, const double* ts, uint64_t n, u
   return FVDB_OK;
 }
 
+// src/hybrid/core.rs:989-1012
+int HybridIndex::vacuum(uint64_t* hnsw_removed, uint64_t* ivf_removed) {
+  if (busy()) return FVDB_E_INVALID;
+  *hnsw_removed = recent_->vacuum();
+  return historical_->vacuum(ivf_removed);
+}
+
 void HybridIndex::export_timestamps(uint64_t* ids, double* ts) const {
   for (size_t i = 0; i < ts_order_.size(); ++i) {
     ids[i] = ts_order_[i];
@@ -214,6 +220,7 @@ void HybridIndex::export_timestamps(uint64_t* ids, double* ts) const {
   }
 }
 
+// src/hybrid/core.rs:600-649 — copies into IVF, never removes from HNSW (:577-581)
 uint64_t HybridIndex::migrate_with_threshold(double threshold_s, double now) {
   // The reference walks the whole timestamps map on every search (:606-617).  Same outcome, O(1) when
   // nothing is due: only ids still living in HNSW alone can migrate, and none is due while the oldest

@@ -63,6 +63,51 @@ void IVFIndex::clear_lists() {
   total_ = 0;
 }
 
+// src/ivf/operations.rs:625-645: every row of a soft-deleted id leaves its list, the survivors keep their order.
+// The lists live in HBM as packed 64-row blocks: copy the survivors out, empty the lists, append them again.
+int IVFIndex::vacuum(uint64_t* removed_out) {
+  const uint64_t removed = deleted_.size();
+  if (removed_out) *removed_out = removed;
+  if (removed == 0) return FVDB_OK;
+  if (dev_) {
+    std::vector<uint64_t> sizes(cfg_.n_clusters);
+    int rc = fvdb_ivf_list_sizes(dev_, sizes.data());
+    if (rc) return rc;
+    std::vector<float> xv, rows;
+    std::vector<uint64_t> xi, ids;
+    std::vector<uint32_t> xc;
+    for (uint32_t c = 0; c < cfg_.n_clusters; ++c) {
+      if (sizes[c] == 0) continue;
+      rows.resize(sizes[c] * (size_t)dim_);
+      ids.resize(sizes[c]);
+      rc = fvdb_ivf_list_export(dev_, c, rows.data(), ids.data(), nullptr);
+      if (rc) return rc;
+      for (uint64_t i = 0; i < sizes[c]; ++i) {
+        if (deleted_.count(ids[i])) continue;
+        xi.push_back(ids[i]);
+        xc.push_back(c);
+        xv.insert(xv.end(), rows.begin() + i * dim_, rows.begin() + (i + 1) * dim_);
+      }
+    }
+    rc = fvdb_ivf_clear(dev_);
+    if (rc) return rc;
+    where_.clear();
+    const uint64_t total_before = total_;
+    total_ = 0;
+    if (!xi.empty()) {
+      uint64_t ok = 0;
+      int err = 0;
+      rc = place(xi.data(), xv.data(), xi.size(), xc.data(), &ok, &err);
+      if (rc) return rc;
+    }
+    total_ = total_before - removed;  // "total_vectors -= removed_count" (:638), counted in ids like the reference
+  } else {
+    total_ -= removed;
+  }
+  deleted_.clear();
+  return FVDB_OK;
+}
+
 int IVFIndex::export_list(uint32_t c, float* rows, uint64_t* ids, uint8_t* live) const {
   if (c >= cfg_.n_clusters) return FVDB_E_INVALID;
   if (!dev_) return FVDB_OK;  // nothing stored yet

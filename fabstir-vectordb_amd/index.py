@@ -84,6 +84,9 @@ HOST_SIGNATURES = {
     "fvh_hnsw_search_dev_end": (i32, [vp, u32, vp, u32, u32, u32, u32, u64p, f32p, u32p]),
     "fvh_hybrid_delete": (i32, [vp, u64, dbl]),
     "fvh_hybrid_migrate": (u64, [vp, dbl, dbl]),
+    "fvh_hybrid_vacuum": (i32, [vp, u64p, u64p]),
+    "fvh_ivf_vacuum": (i32, [vp, u64p]),
+    "fvh_hnsw_vacuum": (u64, [vp]),
     "fvh_hybrid_from_parts": (i32, [vp, u64p, f64p, u64, u64, u64, i32]),
     "fvh_hybrid_timestamp_count": (u64, [vp]),
     "fvh_hybrid_export_timestamps": (None, [vp, u64p, f64p]),
@@ -233,6 +236,11 @@ class IVFIndex(_Base):
     def get_cluster_size(self, c):
         return int(self.lib.fvh_ivf_cluster_size(self.h, c))
 
+    def vacuum(self):
+        out = C.c_uint64(0)
+        self._check(self.lib.fvh_ivf_vacuum(self.h, C.byref(out)))
+        return out.value
+
     def export_list(self, c):
         """Rows (f32), ids and live flags of inverted list `c`, in list-position order (save path)."""
         n = self.get_cluster_size(c)
@@ -371,6 +379,9 @@ class HNSWIndex(_Base):
 
     def is_deleted(self, id):
         return bool(self.lib.fvh_hnsw_is_deleted(self.h, int(id)))
+
+    def vacuum(self):
+        return int(self.lib.fvh_hnsw_vacuum(self.h))
 
     def get_vector_by_id(self, id):
         out = np.empty(int(self.lib.fvh_hnsw_dimension(self.h)), np.float32)
@@ -536,6 +547,12 @@ class HybridIndex(_Base):
 
     def delete(self, id, now=0.0):
         self._check(self.lib.fvh_hybrid_delete(self.h, int(id), float(now)))
+
+    def vacuum(self):
+        """Physically drop soft-deleted vectors from both indexes (src/hybrid/core.rs:989-1012)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.fvh_hybrid_vacuum(self.h, C.byref(a), C.byref(b)))
+        return {"hnsw_removed": a.value, "ivf_removed": b.value, "total_removed": a.value + b.value}
 
     def from_parts(self, ids, timestamps, recent_count, historical_count, ivf_trained):
         """HybridIndex::from_parts (src/hybrid/core.rs:857-877): adopt hnsw() / ivf() as restored by the caller."""

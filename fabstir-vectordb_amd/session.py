@@ -269,6 +269,15 @@ class VectorDbSession:
 
     updateMetadata = update_metadata
 
+    def vacuum(self):
+        """session.rs:793-810: physically remove soft-deleted vectors; returns VacuumStats."""
+        if self.destroyed:
+            raise SessionError("Session already destroyed")
+        try:
+            return self.index.vacuum()
+        except Exception as e:
+            raise SessionError(f"Vacuum failed: {e}") from e
+
     # -- save_to_s5 / load_user_vectors: session.rs:636-697, :99-198 ----------------------------------
     def save_to_s5(self):
         """Chunked index under `session_id/` plus `metadata_map.cbor`; returns the path identifier."""

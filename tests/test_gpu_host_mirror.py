@@ -438,3 +438,82 @@ def test_hybrid_refuses_mutation_while_a_batch_is_in_flight(fv, ctx):
     g.insert_with_timestamp(n, x[0] + 1, now, now)
     g.delete(3, now)
     assert g.migrate_with_threshold(0.5 * DAY, now) > 0
+
+
+def test_hybrid_vacuum_matches_oracle(fv, ctx):
+    # src/hybrid/core.rs:989-1012 -> src/hnsw/operations.rs:176-200 + src/ivf/operations.rs:625-645: soft-deleted
+    # vectors leave the graph (and every neighbour set) and their lists; searches, later inserts and the graph itself
+    # stay identical to the oracle's
+    n, d, nlist = 700, 20, 6
+    x = mixture(n + 60, d, n_comp=6, seed=61)
+    cents = x[:nlist].copy()
+    now = 1000 * DAY
+    ages = np.where(np.random.default_rng(6).random(n + 60) < 0.35, 1 * DAY, 30 * DAY)
+    levels = orc.rng_levels(79, n + 60)
+    kw = dict(max_connections=8, max_connections_layer_0=16, ef_construction=40, n_clusters=nlist, n_probe=3)
+    g, o = fv.HybridIndex(ctx, **kw), orc.HybridIndex(**kw)
+    g.set_ivf_centroids(cents)
+    o.set_ivf_centroids(cents)
+    for i in range(n):
+        g.insert_with_timestamp(i, x[i], now - ages[i], now, int(levels[i]))
+        o.insert_with_timestamp(i, x[i], now - ages[i], now, int(levels[i]))
+    q = mixture(40, d, n_comp=6, seed=62)
+
+    def oracle_batch(k, **kws):
+        ids = np.full((q.shape[0], k), 2**64 - 1, np.uint64)
+        ds = np.full((q.shape[0], k), np.inf, np.float32)
+        cnt = np.zeros(q.shape[0], np.uint32)
+        for b in range(q.shape[0]):
+            r = o.search(q[b], k, **kws)
+            cnt[b] = len(r)
+            ids[b, : len(r)] = r.ids
+            ds[b, : len(r)] = r.distances
+        return ids, ds, cnt
+
+    entry = g.hnsw().entry_point()
+    assert entry == o.hnsw().entry_point()
+    recent = [i for i in range(n) if ages[i] < 7 * DAY and i != entry]
+    hist = [i for i in range(n) if ages[i] >= 7 * DAY]
+    dead = recent[5:45:2] + hist[10:100:3]
+    for i in dead:
+        g.delete(i, now)
+        o.delete(i, now)
+    assert_same_results(g.search(q, 10, now=now, hnsw_ef=30, ivf_n_probe=4), *oracle_batch(10, now=now, hnsw_ef=30, ivf_n_probe=4))
+    before = (g.hnsw().node_count(), g.ivf().total_vectors())
+    stats = g.vacuum()
+    assert stats == {"hnsw_removed": 20, "ivf_removed": 30, "total_removed": 50}
+    assert (o.hnsw().vacuum(), o.ivf().vacuum()) == (20, 30)
+    assert (g.hnsw().node_count(), g.ivf().total_vectors()) == (before[0] - 20, before[1] - 30)
+    assert g.hnsw().active_count() == g.hnsw().node_count() and g.ivf().active_count() == g.ivf().total_vectors()
+    assert g.vacuum()["total_removed"] == 0
+    assert_same_results(g.search(q, 10, now=now, hnsw_ef=30, ivf_n_probe=4), *oracle_batch(10, now=now, hnsw_ef=30, ivf_n_probe=4))
+    # the graph: same survivors, same links
+    ids, lv, off, nb = g.hnsw().export_graph()
+    assert set(ids.tolist()) == set(recent + [entry]) - set(dead) and not np.isin(nb, dead).any()
+    slot = 0
+    for r, l in zip(ids.tolist(), lv.tolist()):
+        for layer in range(l + 1):
+            assert nb[int(off[slot]):int(off[slot + 1])].tolist() == o.hnsw().neighbors(r, layer)
+            slot += 1
+    # lists: survivors in their old order
+    for c in range(nlist):
+        assert g.ivf().export_list(c)[1].tolist() == o.ivf().list_ids(c).tolist()
+    # life goes on: new vectors link into the vacuumed graph / lists identically; a vacuumed id is still on record
+    with pytest.raises(fv.DuplicateVector):
+        g.insert_with_timestamp(dead[0], x[dead[0]], now, now)
+    for i in range(n, n + 60):
+        g.insert_with_timestamp(i, x[i], now - ages[i], now, int(levels[i]))
+        o.insert_with_timestamp(i, x[i], now - ages[i], now, int(levels[i]))
+    assert_same_results(g.search(q, 10, now=now, hnsw_ef=30, ivf_n_probe=4), *oracle_batch(10, now=now, hnsw_ef=30, ivf_n_probe=4))
+    r = g.search_dev(g.ctx.upload(q), q.shape[0], 10, now=now, hnsw_ef=30, ivf_n_probe=4, dim=d)
+    assert_same_results(r, *oracle_batch(10, now=now, hnsw_ef=30, ivf_n_probe=4))
+    # the reference does not repair a vacuumed entry point: its searches fail from then on (src/hnsw/core.rs:418-429)
+    h = fv.HNSWIndex(ctx, max_connections=4, max_connections_layer_0=8, ef_construction=20)
+    for i in range(30):
+        h.insert(i, x[i], int(levels[i]))
+    h.mark_deleted(h.entry_point())
+    assert h.vacuum() == 1
+    with pytest.raises(fv.FvdbError):
+        h.search(q[:2], 3, 10)
+    with pytest.raises(fv.FvdbError):
+        h.insert(1000, x[40], 0)

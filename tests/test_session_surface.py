@@ -110,5 +110,9 @@ def test_session_delete_by_metadata_update_metadata_and_stats():
         s.update_metadata("doc-0", {"n": 1})    # deleted -> metadata gone -> "does not exist"
     with pytest.raises(fv.session.SessionError):
         s.update_metadata("never-added", {})
+    v = s.vacuum()                                                 # session.rs:793-810
+    assert v["total_removed"] == 3 and v["hnsw_removed"] + v["ivf_removed"] == 3
+    st = s.get_stats()
+    assert st["total_deleted_count"] == 0 and st["vector_count"] == 9 and s.search([2.0, 1.0, 0.5], 1)[0]["id"] == "doc-2"
     assert s.delete_by_metadata({}) ["deleted_count"] == 9        # an empty filter matches everything left
     assert s.get_stats()["vector_count"] == 0 and s.search([4.0, 1.0, 0.5], 3) == []
