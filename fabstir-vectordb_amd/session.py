@@ -18,6 +18,7 @@ import struct
 import numpy as np
 
 from .index import HybridIndex
+from .metadata_schema import MetadataSchema, SchemaError
 from .metadata_filter import FilterError, MetadataFilter
 
 # ---------------------------------------------------------------------------------------------
@@ -138,6 +139,7 @@ class VectorDbSession:
         self._rows = {}                                     # u64 row id -> VectorId string
         self.now = now
         self.destroyed = False
+        self.schema = None                                  # MetadataSchema or None (set_schema)
 
     # -- add_vectors: session.rs:340-432 -------------------------------------------------------
     def add_vectors(self, vectors):
@@ -155,6 +157,11 @@ class VectorDbSession:
             training = np.stack([js_array_to_vec_f32(v["vector"]) for v in vectors[:10]])  # first 10 (:367-371)
             self.index.initialize(training)
         for inp in vectors:
+            if self.schema is not None:  # :388-392, before anything of this vector is stored
+                try:
+                    self.schema.validate(inp.get("metadata", {}))
+                except SchemaError as e:
+                    raise SessionError(f"Schema validation failed for vector '{inp['id']}': {e}") from e
             vid = VectorId(inp["id"])
             vec = js_array_to_vec_f32(inp["vector"])
             if vec.size != self.vector_dimension:
@@ -258,6 +265,11 @@ class VectorDbSession:
         if self.destroyed:
             raise SessionError("Session already destroyed")
         key = VectorId(id).to_string()
+        if self.schema is not None:  # :592-598
+            try:
+                self.schema.validate(metadata)
+            except SchemaError as e:
+                raise SessionError(f"Schema validation failed for vector '{id}': {e}") from e
         if key not in self.metadata:
             raise SessionError(f"Vector with id '{id}' does not exist")
         if isinstance(metadata, dict):
@@ -268,6 +280,20 @@ class VectorDbSession:
         self.metadata[key] = md
 
     updateMetadata = update_metadata
+
+    def set_schema(self, schema_json):
+        """session.rs:742-765: a schema in serde's JSON shape (metadata_schema.py), or None to switch validation off."""
+        if self.destroyed:
+            raise SessionError("Session already destroyed")
+        if schema_json is None:
+            self.schema = None
+            return
+        try:
+            self.schema = MetadataSchema.from_json(schema_json)
+        except ValueError as e:
+            raise SessionError(f"Invalid schema format: {e}") from e
+
+    setSchema = set_schema
 
     def vacuum(self):
         """session.rs:793-810: physically remove soft-deleted vectors; returns VacuumStats."""
@@ -293,6 +319,9 @@ class VectorDbSession:
         except chunked.PersistenceError as e:
             raise SessionError(f"Failed to save index: {e}") from e
         self.storage.put(f"{self.session_id}/metadata_map.cbor", chunked.cbor_encode(self.metadata))
+        if self.schema is not None:  # :680-692
+            import json
+            self.storage.put(f"{self.session_id}/schema.json", json.dumps(self.schema.to_json()).encode())
         return self.session_id
 
     saveToS5 = save_to_s5
@@ -326,6 +355,15 @@ class VectorDbSession:
             if not isinstance(md, dict):
                 raise SessionError("Failed to deserialize metadata: expected a map")
             self.metadata = chunked.plain(md)
+        raw = self.storage.get(f"{cid}/schema.json")  # :159-196: replaced by the saved one, or cleared
+        if raw is None:
+            self.schema = None
+        else:
+            import json
+            try:
+                self.schema = MetadataSchema.from_json(json.loads(raw.decode("utf-8")))
+            except (ValueError, UnicodeDecodeError) as e:
+                raise SessionError(f"Failed to deserialize schema: {e}") from e
 
     loadUserVectors = load_user_vectors
 

@@ -315,13 +315,24 @@ def test_session_save_to_s5_and_load_user_vectors(ctx):
                                                                                     "w": 0.1 * i, "nested": {"a": [1, "x", None]}}}
             for i in range(25)]
     s.add_vectors(docs)
+    s.set_schema({"fields": {"n": "Number", "tag": "String", "nested": {"Object": {"a": {"Array": "String"}}}}, "required": ["n"]})
+    with pytest.raises(fv.session.SessionError, match="Schema validation failed for vector 'y'.*index 0 in field 'nested.a'"):
+        s.add_vectors([dict(docs[0], id="y")])       # nested.a holds 1, "x", null: 1 is not a String
+    s.set_schema({"fields": {"n": "Number", "tag": "String"}, "required": ["n"]})
+    with pytest.raises(fv.session.SessionError, match="Missing required field: n"):
+        s.add_vectors([{"id": "x", "vector": [0.0] * 4, "metadata": {"tag": "t"}}])
+    with pytest.raises(fv.session.SessionError, match="expected Number, found String"):
+        s.update_metadata("doc-1", {"n": "one"})
+    assert s.get_stats()["vector_count"] == 25
     s.delete_vector("doc-3")
     before = s.search([4.2, 1.0, 2.0, -2.0], 6)
     assert s.save_to_s5() == "user-1"
+    assert json.loads(st["user-1/schema.json"]) == {"fields": {"n": "Number", "tag": "String"}, "required": ["n"]}
     assert {"user-1/manifest.json", "user-1/metadata_map.cbor", "user-1/chunks/chunk-0.cbor", "user-1/hnsw_nodes.cbor"} <= set(st)
     t = fv.VectorDbSession(ctx, storage=st, session_id="user-2")
     t.add_vectors([{"id": "old", "vector": [0.0, 0.0, 0.0, 0.0], "metadata": {"gone": True}}])
     t.load_user_vectors("user-1")
+    assert t.schema.to_json() == s.schema.to_json()        # the saved schema replaces the session's (:159-196)
     assert t.get_stats() == s.get_stats() and "vec_" + fv.blake3(b"old")[:4].hex() not in t.metadata
     after = t.search([4.2, 1.0, 2.0, -2.0], 6)
     assert after == before and all(r["id"] != "doc-3" for r in after)

@@ -116,3 +116,40 @@ def test_session_delete_by_metadata_update_metadata_and_stats():
     assert st["total_deleted_count"] == 0 and st["vector_count"] == 9 and s.search([2.0, 1.0, 0.5], 1)[0]["id"] == "doc-2"
     assert s.delete_by_metadata({}) ["deleted_count"] == 9        # an empty filter matches everything left
     assert s.get_stats()["vector_count"] == 0 and s.search([4.0, 1.0, 0.5], 3) == []
+
+
+def test_metadata_schema():
+    # src/core/schema.rs (its unit tests :227-293) and bindings/node/test/schema-validation.test.js
+    from fabstir_vectordb_amd.metadata_schema import FieldType, MetadataSchema, SchemaError
+    assert [FieldType.from_json(j).type_name() for j in ("String", "Number", "Boolean", {"Array": "String"}, {"Object": {}})] == \
+        ["String", "Number", "Boolean", "Array<String>", "Object"]
+    ok = lambda t, v: FieldType.from_json(t).validate_value("test", v)  # noqa: E731
+
+    def bad(t, v):
+        with pytest.raises(SchemaError) as e:
+            ok(t, v)
+        return str(e.value)
+
+    ok("String", "hello"), ok("String", None), ok("Number", 123), ok("Number", 123.45), ok("Boolean", True), ok("Boolean", False)
+    ok({"Array": "String"}, ["a", "b", None]), ok({"Object": {"name": "String"}}, {"name": "x", "extra": 1})
+    assert bad("String", 123) == "Invalid type for field 'test': expected String, found Number"
+    assert bad("Number", "123") == "Invalid type for field 'test': expected Number, found String"
+    assert bad("Number", True).endswith("found Boolean") and bad("Boolean", "true").endswith("found String")
+    assert bad({"Array": "String"}, ["a", 123, "c"]) == \
+        "Invalid array element at index 1 in field 'test': expected String, found Number"
+    assert bad({"Array": "String"}, "a") == "Invalid type for field 'test': expected Array<String>, found String"
+    assert bad({"Object": {"name": "String"}}, {"name": 5}) == "Invalid type for field 'test.name': expected String, found Number"
+    assert bad({"Array": {"Array": "Number"}}, [[1, "x"]]).startswith("Invalid array element at index 1 in field 'test[0]'")
+    s = MetadataSchema.from_json({"fields": {"title": "String", "views": "Number", "published": "Boolean", "tags": {"Array": "String"}},
+                                  "required": ["title", "views"]})
+    s.validate({"title": "Valid Document", "views": 500, "published": True, "tags": ["valid", "test"]})
+    s.validate({"title": "Minimal Document", "views": 50, "unknown": object()})  # optional / unknown fields are not checked
+    for md, msg in (({"views": 1}, "Missing required field: title"), ({"title": "T", "views": "not-a-number"},
+                    "expected Number, found String"), ([1], "Invalid type for field 'metadata': expected Object, found Array")):
+        with pytest.raises(SchemaError) as e:
+            s.validate(md)
+        assert msg in str(e.value)
+    assert MetadataSchema.from_json(s.to_json()).to_json() == s.to_json()
+    for j in ({"fields": {"a": "string"}, "required": []}, {"fields": {}}, {"required": []}, {"fields": {"a": {"type": "string"}}, "required": []}):
+        with pytest.raises(ValueError):
+            MetadataSchema.from_json(j)
