@@ -16,5 +16,5 @@ from .index import IVFIndex, HNSWIndex, HybridIndex, SearchResults, load_host  #
 from . import sharded  # noqa: F401,E402
 from . import metadata_filter  # noqa: F401,E402
 from . import session  # noqa: F401,E402
-from .session import VectorDbSession, VectorId, blake3, rest_search  # noqa: F401,E402
+from .session import VectorDbSession, VectorId, blake3, rest_search, rest_insert_vector, rest_batch_insert  # noqa: F401,E402
 from . import chunked  # noqa: F401,E402

@@ -412,8 +412,8 @@ def rest_search(index, request, id_of_row=None, now=0.0):
     HybridSearchConfig but calls `hybrid_index.search(&vector, k)`, :631-634)."""
     import time
     vec = np.asarray(request["vector"], dtype=np.float32)
-    if vec.size == 0 or not np.all(np.isfinite(vec)):
-        raise ValueError("Invalid vector")  # validate_vector -> 400
+    if vec.size == 0:
+        raise ValueError("Vector cannot be empty")  # validate_vector (:741-746) -> 400
     k = int(request["k"])
     opts = request.get("options") or {}
     t0 = time.perf_counter()
@@ -431,3 +431,43 @@ def rest_search(index, request, id_of_row=None, now=0.0):
     sr, sh = opts.get("search_recent", True), opts.get("search_historical", True)
     return {"results": results, "search_time_ms": (time.perf_counter() - t0) * 1e3,
             "indices_searched": 2 if (sr and sh) else 1, "partial_results": False}
+
+
+def rest_insert_vector(index, request, now=0.0, rows=None):
+    """POST /api/v1/vectors (src/api/rest.rs:392-446) for {"id": str, "vector": [...], "metadata": any}: the vector
+    goes in with timestamp = now, so it lands in the recent (HNSW) index.  Returns (201, body); an empty vector raises
+    ValueError (400), an index error RuntimeError (500) with the handler's message.  `rows`: dict filled with
+    row id -> request id, for rest_search's id_of_row."""
+    from .chunked import format_timestamp
+    vec = np.asarray(request["vector"], dtype=np.float32)
+    if vec.size == 0:
+        raise ValueError("Vector cannot be empty")
+    vid = VectorId(request["id"])
+    try:
+        index.insert_with_timestamp(vid.row_id(), vec, now, now)
+    except Exception as e:
+        raise RuntimeError(f"Failed to add vector to index: {e}") from e
+    if rows is not None:
+        rows[vid.row_id()] = request["id"]
+    # chrono's to_rfc3339() writes UTC as "+00:00" (its serde form, used on disk, writes "Z")
+    return 201, {"id": request["id"], "index": "recent", "timestamp": format_timestamp(now)[:-1] + "+00:00"}
+
+
+def rest_batch_insert(index, request, now=0.0, rows=None):
+    """POST /api/v1/vectors/batch (src/api/rest.rs:449-531): per-vector outcome, never an error as a whole."""
+    ok, errors = 0, []
+    for v in request["vectors"]:
+        vec = np.asarray(v["vector"], dtype=np.float32)
+        if vec.size == 0:
+            errors.append({"id": v["id"], "error": "Vector cannot be empty"})
+            continue
+        vid = VectorId(v["id"])
+        try:
+            index.insert_with_timestamp(vid.row_id(), vec, now, now)
+        except Exception as e:  # noqa: BLE001
+            errors.append({"id": v["id"], "error": f"Index error: {e}"})
+            continue
+        if rows is not None:
+            rows[vid.row_id()] = v["id"]
+        ok += 1
+    return {"successful": ok, "failed": len(errors), "errors": errors}

@@ -153,3 +153,27 @@ def test_metadata_schema():
     for j in ({"fields": {"a": "string"}, "required": []}, {"fields": {}}, {"required": []}, {"fields": {"a": {"type": "string"}}, "required": []}):
         with pytest.raises(ValueError):
             MetadataSchema.from_json(j)
+
+
+@pytest.mark.gpu
+def test_rest_insert_and_batch_insert():
+    # src/api/rest.rs:392-531 (insert_vector -> 201 {"id", "index": "recent", "timestamp"}; batch_insert counts per
+    # vector), then /search finds them (:599-677)
+    ctx = fv.Context(0)
+    ix = fv.HybridIndex(ctx)
+    ix.initialize([[float(i), 0.0, 1.0] for i in range(12)])
+    rows, now = {}, 1764325230.5
+    code, body = fv.rest_insert_vector(ix, {"id": "a", "vector": [1.0, 0.0, 1.0], "metadata": {}}, now=now, rows=rows)
+    assert code == 201 and body == {"id": "a", "index": "recent", "timestamp": "2025-11-28T10:20:30.500+00:00"}
+    with pytest.raises(ValueError, match="Vector cannot be empty"):
+        fv.rest_insert_vector(ix, {"id": "e", "vector": []}, now=now)
+    with pytest.raises(RuntimeError, match="Failed to add vector to index"):
+        fv.rest_insert_vector(ix, {"id": "a", "vector": [1.0, 0.0, 1.0]}, now=now)     # duplicate
+    r = fv.rest_batch_insert(ix, {"vectors": [{"id": "b", "vector": [2.0, 0.0, 1.0]}, {"id": "c", "vector": []},
+                                              {"id": "a", "vector": [9.0, 9.0, 9.0]}, {"id": "d", "vector": [3.0, 0.0]},
+                                              {"id": "f", "vector": [4.0, 0.0, 1.0]}]}, now=now, rows=rows)
+    assert (r["successful"], r["failed"]) == (2, 3) and [e["id"] for e in r["errors"]] == ["c", "a", "d"]
+    assert r["errors"][0]["error"] == "Vector cannot be empty" and r["errors"][1]["error"].startswith("Index error: ")
+    assert ix.recent_count() == 3 and ix.historical_count() == 0
+    out = fv.rest_search(ix, {"vector": [2.1, 0.0, 1.0], "k": 5}, id_of_row=rows.get, now=now)
+    assert [x["id"] for x in out["results"]] == ["b", "a", "f"]
