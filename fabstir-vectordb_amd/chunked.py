@@ -740,7 +740,10 @@ def load_index_chunked(ctx, storage, path, now=0.0, **config):
     tval = np.asarray([parse_timestamp(v) for _, v in pairs], np.float64)
     for k, _ in pairs:
         table.setdefault(row_id(_id_bytes(k)), _id_bytes(k))
-    index.from_parts(tid, tval, meta["recent_count"], meta["historical_count"], bool(meta.get("ivf_trained", False)))
+    try:
+        index.from_parts(tid, tval, meta["recent_count"], meta["historical_count"], bool(meta.get("ivf_trained", False)))
+    except FvdbError as e:
+        raise PersistenceError("InvalidData", f"Failed to reconstruct index: {e}") from e
     # 10. deleted ids are stored as display strings and hashed again on the way in (:675-682) — best effort
     for s in manifest.get("deleted_vectors") or []:
         try:
