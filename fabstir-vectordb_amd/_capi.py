@@ -104,6 +104,13 @@ SIGNATURES = {
     "fvdb_graph_kernel_times": (i32, [vp, f32p, u32p, u64p, u64p]),
     "fvdb_scorer_launch": (i32, [vp, u32, u32]),
     "fvdb_scorer_wait": (i32, [vp]),
+    "fvdb_top_k_indices": (i32, [vp, f32p, u32, u64, u32, u64p, u32p]),
+    "fvdb_top_k_indices_heap": (i32, [vp, f32p, u32, u64, u32, u64p, u32p]),
+    "fvdb_top_k_indices_dev": (i32, [vp, vp, u32, u64, u32, i32, vp, vp]),
+    "fvdb_streaming_top_k": (i32, [vp, u64p, f32p, u32, u64, u32, u64p, f32p, u32p]),
+    "fvdb_streaming_top_k_dev": (i32, [vp, vp, vp, u32, u64, u32, vp, vp, vp]),
+    "fvdb_merge_search_results": (i32, [vp, u64p, f32p, u32, u64, u32, u64p, f32p, u32p]),
+    "fvdb_merge_search_results_dev": (i32, [vp, vp, vp, u32, u64, u32, vp, vp, vp]),
 }
 
 _lib = None

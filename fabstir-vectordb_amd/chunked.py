@@ -442,6 +442,49 @@ def manifest_from_json(text):
         for field in ("chunk_id", "vector_count", "byte_size", "vector_id_range"):
             if not isinstance(c, dict) or field not in c:
                 raise PersistenceError("Deserialization", f"Failed to parse manifest: chunk missing `{field}`")
+
+    def bad(what):
+        return PersistenceError("Deserialization", f"Failed to parse manifest: {what}")
+
+    def is_int(v):
+        return isinstance(v, int) and not isinstance(v, bool)
+
+    # HNSWManifest (src/core/chunk.rs:152-160): entry_point [u8; 32], layers Vec<LayerMetadata>, node_chunk_map
+    hs = m["hnsw_structure"]
+    if hs is not None:
+        if not isinstance(hs, dict):
+            raise bad("hnsw_structure: expected a map")
+        for field, typ in (("entry_point", list), ("layers", list), ("node_chunk_map", dict)):
+            if field not in hs:
+                raise bad(f"hnsw_structure: missing field `{field}`")
+            if not isinstance(hs[field], typ):
+                raise bad(f"hnsw_structure: invalid type for `{field}`")
+        ep = hs["entry_point"]
+        if len(ep) != 32 or not all(is_int(b) and 0 <= b <= 255 for b in ep):
+            raise bad("hnsw_structure.entry_point: expected 32 bytes")
+    # IVFManifest (:179-185): centroids Vec<Vec<f32>> (rectangular for set_trained), cluster_assignments usize -> chunks
+    iv = m["ivf_structure"]
+    if iv is not None:
+        if not isinstance(iv, dict):
+            raise bad("ivf_structure: expected a map")
+        for field, typ in (("centroids", list), ("cluster_assignments", dict)):
+            if field not in iv:
+                raise bad(f"ivf_structure: missing field `{field}`")
+            if not isinstance(iv[field], typ):
+                raise bad(f"ivf_structure: invalid type for `{field}`")
+        width = None
+        for c in iv["centroids"]:
+            if not isinstance(c, list) or not all(isinstance(v, (int, float)) and not isinstance(v, bool) for v in c):
+                raise bad("ivf_structure.centroids: expected arrays of numbers")
+            if width is not None and len(c) != width:
+                raise bad("ivf_structure.centroids: rows of different lengths")
+            width = len(c)
+        for key in iv["cluster_assignments"]:
+            if not (isinstance(key, str) and key.isascii() and key.isdigit()):  # a usize map key as serde_json writes it
+                raise bad(f"ivf_structure.cluster_assignments: invalid cluster id {key!r}")
+    dv = m["deleted_vectors"]
+    if dv is not None and not isinstance(dv, list):
+        raise bad("deleted_vectors: expected an array")
     return m
 
 

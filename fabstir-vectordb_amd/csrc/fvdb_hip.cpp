@@ -5,7 +5,10 @@
 #include "../../include/fvdb.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +22,7 @@
 #include "kernels_scan.h"
 #include "kernels_coarse.h"
 #include "kernels_mfma.h"
+#include "kernels_util.h"
 
 using namespace fvdb;
 
@@ -73,7 +77,12 @@ struct fvdb_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cus = 256;
-  std::string err;
+  std::string err;   // last failure; written under err_mu (searches may fail on several host threads)
+  std::mutex err_mu;
+  void set_err(std::string m) {
+    std::lock_guard<std::mutex> lk(err_mu);
+    err = std::move(m);
+  }
   HBuf h_stage;     // host->device staging for host-pointer entry points
   int profiling = 0;
 };
@@ -82,14 +91,14 @@ struct fvdb_ctx {
   do {                                                                                        \
     hipError_t e_ = (call);                                                                   \
     if (e_ != hipSuccess) {                                                                   \
-      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+      (ctx)->set_err(std::string(#call) + ": " + hipGetErrorString(e_));                      \
       return e_ == hipErrorOutOfMemory ? FVDB_E_OOM : FVDB_E_HIP;                             \
     }                                                                                         \
   } while (0)
 
 #define FAIL(ctx, code, msg) \
   do {                       \
-    (ctx)->err = (msg);      \
+    (ctx)->set_err(msg);     \
     return (code);           \
   } while (0)
 
@@ -170,9 +179,15 @@ struct Pool {
   }
 };
 
-// Per-search scratch of an IVF index.  One set lives in the index itself; spare sets let searches on other
-// streams be in flight at the same time (fvdb_ivf_search_dev_slot swaps a spare set in for the duration of the call).
+// Per-search scratch of an IVF index.  Set 0 lives in the index itself (also used by the mutating entry points);
+// sets 1..7 serve the other explicit slots of the *_slot entry points; a further pool of leased sets, each with a
+// stream of its own, serves the blocking host-pointer searches, so any number of host threads may search one index
+// at once (reference: searches hold a read guard, bindings/node/src/session.rs:253).  A search never modifies the
+// index object: the scratch set and the stream it runs on are passed down explicitly (Env).
 struct IvfScratch {
+  std::mutex enq;  // held while one search's launches are enqueued: searches sharing a set are ordered by the stream
+  bool pend_filter = false;
+  bool pending_profile = false, pend_coarse = false, pend_fine = false, collecting = false;
   DBuf s_qnorm, s_A;
   DBuf s_qh, s_qn2, s_thr, s_tA, s_pa, s_surv, s_scnt, s_fail, s_mslots, s_sdist;
   DBuf s_q, s_cpart, s_probes, s_cnt, s_fill, s_eoff, s_ioff, s_entries, s_part, s_scalars, s_ceoff, s_cioff;
@@ -193,6 +208,13 @@ struct IvfScratch {
 struct fvdb_ivf : IvfScratch {
   static constexpr uint32_t kSlots = 8;
   IvfScratch spare[kSlots - 1];  // slots 1..7
+  // leased sets for blocking searches called from several host threads: each has its own stream (a private context)
+  static constexpr uint32_t kLeases = 8;
+  IvfScratch lease_set[kLeases];
+  fvdb_ctx* lease_ctx[kLeases] = {};
+  uint32_t lease_busy = 0;  // bit i: set i is out (under mu)
+  std::mutex mu;            // list table upload, lease bookkeeping, AUTO-mode counters
+  std::condition_variable lease_cv;
   fvdb_ctx* ctx = nullptr;
   uint32_t d = 0, dpad = 0, d4 = 0, nlist = 0;
   bool trained = false;
@@ -233,10 +255,17 @@ struct fvdb_ivf : IvfScratch {
   fvdb_search_stats last_stats{};
   // coarse scan, coarse merge, plan, fine scan, fine merge, [5] the matrix-core filter kernel alone (inside fine scan)
   float stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  bool pend_filter = false;
-  bool pending_profile = false, pend_coarse = false, pend_fine = false, collecting = false;
   uint64_t stage_calls = 0;
 };
+
+namespace {
+// what a search runs with: the stream (context) its launches go to and the scratch set they may touch
+struct Env {
+  fvdb_ctx* ctx;
+  IvfScratch* S;
+};
+inline IvfScratch& slot_scratch(fvdb_ivf* ivf, uint32_t slot) { return slot == 0 ? *ivf : ivf->spare[slot - 1]; }
+}  // namespace
 
 struct fvdb_store {
   fvdb_ctx* ctx = nullptr;
@@ -261,6 +290,7 @@ struct fvdb_graph {
   uint64_t n_deleted = 0;
   hipEvent_t kev[64][2] = {};
   uint32_t kev_n = 0;   // launches recorded since the last fvdb_graph_kernel_times call
+  std::mutex mu;        // launch bookkeeping: searches in different slots may come from different host threads
   uint64_t last_rows = 0;
 };
 
@@ -345,6 +375,7 @@ constexpr size_t kScalarsBytes = 64;
 
 int upload_table(fvdb_ivf* ivf) {
   fvdb_ctx* ctx = ivf->ctx;
+  std::lock_guard<std::mutex> lk(ivf->mu);  // concurrent searches after a mutation: one of them uploads
   if (!ivf->table_dirty) return FVDB_OK;
   std::vector<uint32_t> off(ivf->nlist + 1, 0), blocks;
   std::vector<uint32_t> glob(ivf->nlist, 0);
@@ -373,71 +404,74 @@ int upload_table(fvdb_ivf* ivf) {
 }
 
 // queries as [B][dpad] in HBM: q_dev itself when d is a multiple of 4, else a padded copy
-int padded_queries(fvdb_ivf* ivf, const float* q_dev, uint32_t B, const float** out) {
-  fvdb_ctx* ctx = ivf->ctx;
+int padded_queries(fvdb_ivf* ivf, const Env& E, const float* q_dev, uint32_t B, const float** out) {
+  fvdb_ctx* ctx = E.ctx;
+  IvfScratch& S = *E.S;
   if (ivf->d == ivf->dpad) {
     *out = q_dev;
     return FVDB_OK;
   }
-  HIPCHK(ctx, ivf->s_q.ensure((size_t)B * ivf->dpad * 4));
+  HIPCHK(ctx, S.s_q.ensure((size_t)B * ivf->dpad * 4));
   const uint64_t tot = (uint64_t)B * ivf->dpad;
   hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, ctx->stream, q_dev, ivf->d, ivf->dpad,
-                     (uint64_t)B, ivf->s_q.as<float>());
-  *out = ivf->s_q.as<float>();
+                     (uint64_t)B, S.s_q.as<float>());
+  *out = S.s_q.as<float>();
   return FVDB_OK;
 }
 
 // Coarse stage: rank the centroid table for B queries, keep kc nearest per query.
 // Writes u32 cluster ids to out_probes[B][kc] (probe order) and, optionally, their distances.
-int run_coarse(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t kc, uint32_t* out_probes, float* out_dist) {
-  fvdb_ctx* ctx = ivf->ctx;
+int run_coarse(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, uint32_t kc, uint32_t* out_probes,
+               float* out_dist) {
+  fvdb_ctx* ctx = E.ctx;
+  IvfScratch& S = *E.S;
   static const bool env_exact = getenv("FVDB_COARSE_EXACT") != nullptr;  // tuning aid
   if (ivf->coarse_mode == 0 && !env_exact && ivf->dpad % 16 == 0 && kc <= 48 && ivf->nlist >= 64 && B > 0 &&
       (uint64_t)B * ivf->nlist < (1ull << 31)) {
     // matrix cores propose 64 candidates per query; the reference's arithmetic decides (kernels_coarse.h)
     const uint32_t nlist = ivf->nlist;
     const float* cpad = ivf->d == ivf->dpad ? ivf->d_centroids_rm.as<float>() : ivf->d_cent_pad.as<float>();
-    HIPCHK(ctx, ivf->s_qnorm.ensure((size_t)B * 4));
-    HIPCHK(ctx, ivf->s_A.ensure((size_t)B * nlist * 4));
-    if (ctx->profiling) (void)hipEventRecord(ivf->sev[0], ctx->stream);
+    HIPCHK(ctx, S.s_qnorm.ensure((size_t)B * 4));
+    HIPCHK(ctx, S.s_A.ensure((size_t)B * nlist * 4));
+    if (ctx->profiling) (void)hipEventRecord(S.sev[0], ctx->stream);
     hipLaunchKernelGGL(row_sqnorm_wave_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, qpad, ivf->dpad, ivf->dpad, B,
-                       ivf->s_qnorm.as<float>());
+                       S.s_qnorm.as<float>());
     const uint32_t waves = cdiv(B, 32) * cdiv(nlist, 64);
     hipLaunchKernelGGL(coarse_gemm_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, qpad, cpad,
-                       ivf->s_qnorm.as<float>(), ivf->d_cnorm.as<float>(), B, nlist, ivf->dpad, ivf->s_A.as<float>());
-    if (ctx->profiling) (void)hipEventRecord(ivf->sev[1], ctx->stream);
-    hipLaunchKernelGGL(coarse_select_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, ivf->s_A.as<float>(), qpad, cpad,
-                       ivf->s_qnorm.as<float>(), ivf->d_cnmax.as<float>(), B, nlist, ivf->d, ivf->dpad, 64u, kc,
+                       S.s_qnorm.as<float>(), ivf->d_cnorm.as<float>(), B, nlist, ivf->dpad, S.s_A.as<float>());
+    if (ctx->profiling) (void)hipEventRecord(S.sev[1], ctx->stream);
+    hipLaunchKernelGGL(coarse_select_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, S.s_A.as<float>(), qpad, cpad,
+                       S.s_qnorm.as<float>(), ivf->d_cnmax.as<float>(), B, nlist, ivf->d, ivf->dpad, 64u, kc,
                        out_probes, out_dist, ivf->s_fallbacks.as<uint32_t>());
-    if (ctx->profiling) (void)hipEventRecord(ivf->sev[2], ctx->stream);
+    if (ctx->profiling) (void)hipEventRecord(S.sev[2], ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     return FVDB_OK;
   }
   const uint32_t cblocks = ivf->cpool.used_blocks;
   const uint32_t segb = 1, Q = q_for(kc);
   const uint32_t maxsegs = cblocks;
-  HIPCHK(ctx, ivf->s_cpart.ensure((size_t)B * maxsegs * kc * 8));
-  HIPCHK(ctx, ivf->s_entries.ensure((size_t)B * std::max<uint32_t>(kc, 1) * 8));
-  HIPCHK(ctx, ivf->s_ceoff.ensure(16));
-  HIPCHK(ctx, ivf->s_cioff.ensure(16));
-  HIPCHK(ctx, ivf->s_scalars.ensure(kScalarsBytes));
-  uint32_t* scal = ivf->s_scalars.as<uint32_t>();
+  HIPCHK(ctx, S.s_cpart.ensure((size_t)B * maxsegs * kc * 8));
+  HIPCHK(ctx, S.s_entries.ensure((size_t)B * std::max<uint32_t>(kc, 1) * 8));
+  HIPCHK(ctx, S.s_ceoff.ensure(16));
+  HIPCHK(ctx, S.s_cioff.ensure(16));
+  HIPCHK(ctx, S.s_scalars.ensure(kScalarsBytes));
+  uint32_t* scal = S.s_scalars.as<uint32_t>();
   hipLaunchKernelGGL(plan_all_kernel, dim3(cdiv(std::max<uint32_t>(B, 1), 256)), dim3(256), 0, ctx->stream, B, cblocks,
-                     segb, Q, ivf->s_ceoff.as<uint32_t>(), ivf->s_cioff.as<uint32_t>(), ivf->s_entries.as<uint2>(),
+                     segb, Q, S.s_ceoff.as<uint32_t>(), S.s_cioff.as<uint32_t>(), S.s_entries.as<uint2>(),
                      scal + 0, scal + 1);
   ScanLaunch s{ivf->cpool.view(), ivf->c_off.as<uint32_t>(), ivf->c_blocks.as<uint32_t>(), 1,
-               ivf->s_ceoff.as<uint32_t>(), ivf->s_cioff.as<uint32_t>(), ivf->s_entries.as<uint2>(), scal + 0,
-               scal + 1, qpad, ivf->dpad, segb, kc, 1, maxsegs, ivf->s_cpart.as<uint2>(),
+               S.s_ceoff.as<uint32_t>(), S.s_cioff.as<uint32_t>(), S.s_entries.as<uint2>(), scal + 0,
+               scal + 1, qpad, ivf->dpad, segb, kc, 1, maxsegs, S.s_cpart.as<uint2>(),
                cdiv(cblocks, segb) * cdiv(B, Q)};
-  if (ctx->profiling) (void)hipEventRecord(ivf->sev[0], ctx->stream);
+  if (ctx->profiling) (void)hipEventRecord(S.sev[0], ctx->stream);
   launch_scan(ctx, s, ROLE_COARSE);
-  if (ctx->profiling) (void)hipEventRecord(ivf->sev[1], ctx->stream);
+  if (ctx->profiling) (void)hipEventRecord(S.sev[1], ctx->stream);
   MergeArgs m{};
   m.pool = ivf->cpool.view();
   m.lists = ListTable{ivf->c_off.as<uint32_t>(), ivf->c_blocks.as<uint32_t>(), 1};
   m.probes = nullptr;
   m.glob_blocks = ivf->c_glob.as<uint32_t>();
-  m.part = ivf->s_cpart.as<uint2>();
+  m.part = S.s_cpart.as<uint2>();
   m.B = B;
   m.k = kc;
   m.nprobe = 1;
@@ -446,7 +480,7 @@ int run_coarse(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t kc, uint32
   m.out_probes = out_probes;
   m.out_dist = out_dist;
   launch_merge(ctx, m);
-  if (ctx->profiling) (void)hipEventRecord(ivf->sev[2], ctx->stream);
+  if (ctx->profiling) (void)hipEventRecord(S.sev[2], ctx->stream);
   HIPCHK(ctx, hipGetLastError());
   return FVDB_OK;
 }
@@ -463,46 +497,47 @@ uint32_t pick_segb(fvdb_ivf* ivf, uint32_t B, uint32_t nprobe) {
 }
 
 // Fine stage for B queries whose probes[B][np] are already in HBM: every row scored with the reference's fold.
-int run_fine_exact(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t np, const uint32_t* probes,
-                   uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys, int role,
-                   bool events = true) {
-  fvdb_ctx* ctx = ivf->ctx;
+int run_fine_exact(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, uint32_t k, uint32_t np,
+                   const uint32_t* probes, uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys,
+                   int role, bool events = true) {
+  fvdb_ctx* ctx = E.ctx;
+  IvfScratch& S = *E.S;
   const uint32_t nlist = ivf->nlist;
   const uint32_t segb = pick_segb(ivf, B, np), Q = q_for(k);
   const uint32_t maxsegs = std::max<uint32_t>(1, cdiv(ivf->max_list_blocks, segb));
   const uint64_t part_elems = (uint64_t)B * np * maxsegs * k;
   if (part_elems >= (1ull << 32)) FAIL(ctx, FVDB_E_UNSUPPORTED, "batch too large for one launch (sub-batch it)");
-  HIPCHK(ctx, ivf->s_cnt.ensure((size_t)nlist * 4));
-  HIPCHK(ctx, ivf->s_fill.ensure((size_t)nlist * 4));
-  HIPCHK(ctx, ivf->s_eoff.ensure((size_t)(nlist + 1) * 4));
-  HIPCHK(ctx, ivf->s_ioff.ensure((size_t)(nlist + 1) * 4));
-  HIPCHK(ctx, ivf->s_entries.ensure((size_t)B * np * 8));
-  HIPCHK(ctx, ivf->s_part.ensure((size_t)part_elems * 8));
-  HIPCHK(ctx, ivf->s_scalars.ensure(kScalarsBytes));
-  uint32_t* scal = ivf->s_scalars.as<uint32_t>();
+  HIPCHK(ctx, S.s_cnt.ensure((size_t)nlist * 4));
+  HIPCHK(ctx, S.s_fill.ensure((size_t)nlist * 4));
+  HIPCHK(ctx, S.s_eoff.ensure((size_t)(nlist + 1) * 4));
+  HIPCHK(ctx, S.s_ioff.ensure((size_t)(nlist + 1) * 4));
+  HIPCHK(ctx, S.s_entries.ensure((size_t)B * np * 8));
+  HIPCHK(ctx, S.s_part.ensure((size_t)part_elems * 8));
+  HIPCHK(ctx, S.s_scalars.ensure(kScalarsBytes));
+  uint32_t* scal = S.s_scalars.as<uint32_t>();
   const uint32_t n = B * np;
-  HIPCHK(ctx, hipMemsetAsync(ivf->s_cnt.p, 0, (size_t)nlist * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(S.s_cnt.p, 0, (size_t)nlist * 4, ctx->stream));
   hipLaunchKernelGGL(plan_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, probes, n,
-                     ivf->s_cnt.as<uint32_t>());
-  hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ivf->s_cnt.as<uint32_t>(),
-                     ivf->t_off.as<uint32_t>(), ivf->t_len.as<uint32_t>(), nlist, segb, Q, ivf->s_eoff.as<uint32_t>(),
-                     ivf->s_ioff.as<uint32_t>(), ivf->s_fill.as<uint32_t>(), scal + 2, scal + 3,
+                     S.s_cnt.as<uint32_t>());
+  hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, S.s_cnt.as<uint32_t>(),
+                     ivf->t_off.as<uint32_t>(), ivf->t_len.as<uint32_t>(), nlist, segb, Q, S.s_eoff.as<uint32_t>(),
+                     S.s_ioff.as<uint32_t>(), S.s_fill.as<uint32_t>(), scal + 2, scal + 3,
                      (unsigned long long*)(scal + 4));
   hipLaunchKernelGGL(plan_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, probes, n, np,
-                     ivf->s_eoff.as<uint32_t>(), ivf->s_fill.as<uint32_t>(), ivf->s_entries.as<uint2>());
-  if (ctx->profiling && events) (void)hipEventRecord(ivf->sev[3], ctx->stream);
+                     S.s_eoff.as<uint32_t>(), S.s_fill.as<uint32_t>(), S.s_entries.as<uint2>());
+  if (ctx->profiling && events) (void)hipEventRecord(S.sev[3], ctx->stream);
   ScanLaunch s{ivf->pool.view(), ivf->t_off.as<uint32_t>(), ivf->t_blocks.as<uint32_t>(), nlist,
-               ivf->s_eoff.as<uint32_t>(), ivf->s_ioff.as<uint32_t>(), ivf->s_entries.as<uint2>(), scal + 2,
-               scal + 3, qpad, ivf->dpad, segb, k, np, maxsegs, ivf->s_part.as<uint2>()};
+               S.s_eoff.as<uint32_t>(), S.s_ioff.as<uint32_t>(), S.s_entries.as<uint2>(), scal + 2,
+               scal + 3, qpad, ivf->dpad, segb, k, np, maxsegs, S.s_part.as<uint2>()};
   s.f16 = ivf->f16;
   launch_scan(ctx, s, role);
-  if (ctx->profiling && events) (void)hipEventRecord(ivf->sev[4], ctx->stream);
+  if (ctx->profiling && events) (void)hipEventRecord(S.sev[4], ctx->stream);
   MergeArgs m{};
   m.pool = ivf->pool.view();
   m.lists = ListTable{ivf->t_off.as<uint32_t>(), ivf->t_blocks.as<uint32_t>(), nlist};
   m.probes = probes;
   m.glob_blocks = ivf->t_glob.as<uint32_t>();
-  m.part = ivf->s_part.as<uint2>();
+  m.part = S.s_part.as<uint2>();
   m.B = B;
   m.k = k;
   m.nprobe = np;
@@ -513,7 +548,7 @@ int run_fine_exact(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uin
   m.out_counts = out_counts;
   m.out_keys = out_keys;
   launch_merge(ctx, m);
-  if (ctx->profiling && events) (void)hipEventRecord(ivf->sev[5], ctx->stream);
+  if (ctx->profiling && events) (void)hipEventRecord(S.sev[5], ctx->stream);
   HIPCHK(ctx, hipGetLastError());
   return FVDB_OK;
 }
@@ -538,9 +573,10 @@ void launch_mfma(fvdb_ctx* ctx, const MfmaScanArgs& a, int M, bool f16, uint32_t
 }
 }  // namespace
 
-int run_fine_mfma(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t np, const uint32_t* probes,
-                  uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys) {
-  fvdb_ctx* ctx = ivf->ctx;
+int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, uint32_t k, uint32_t np,
+                  const uint32_t* probes, uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys) {
+  fvdb_ctx* ctx = E.ctx;
+  IvfScratch& S = *E.S;
   // tuning aids
   static const int M_env = env_u("FVDB_MFMA_M", 2), segb_env = env_u("FVDB_MFMA_SEGB", 0),
                    segbA_env = env_u("FVDB_MFMA_SEGB_A", 1), capA_env = env_u("FVDB_MFMA_CAP_A", 8), wgs_env = env_u("FVDB_MFMA_WGS_PER_CU", 2);
@@ -553,41 +589,41 @@ int run_fine_mfma(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint
   const uint32_t fsegb = pick_segb(ivf, B, np), fmaxsegs = std::max<uint32_t>(1, cdiv(ivf->max_list_blocks, fsegb));
   const uint64_t fpart = (uint64_t)B * np * fmaxsegs * k;
   if (fpart >= (1ull << 32)) FAIL(ctx, FVDB_E_UNSUPPORTED, "batch too large for one launch (sub-batch it)");
-  HIPCHK(ctx, ivf->s_qh.ensure((size_t)(B + 1) * ivf->dpad * 2));
-  HIPCHK(ctx, ivf->s_qn2.ensure((size_t)B * 4));
-  HIPCHK(ctx, ivf->s_thr.ensure((size_t)B * 4));
-  HIPCHK(ctx, ivf->s_tA.ensure((size_t)B * 4));
-  HIPCHK(ctx, ivf->s_pa.ensure((size_t)B * 4));
-  HIPCHK(ctx, ivf->s_mslots.ensure((size_t)B * 64 * 4));
-  HIPCHK(ctx, ivf->s_surv.ensure((size_t)B * cmax * 8));
-  HIPCHK(ctx, ivf->s_sdist.ensure((size_t)B * cmax * 4));
-  HIPCHK(ctx, ivf->s_scnt.ensure((size_t)(B + 2) * 4));  // [B] survivor counts, then nfail and the rescan queue head
-  HIPCHK(ctx, ivf->s_fail.ensure((size_t)B * 4));
-  HIPCHK(ctx, ivf->s_part.ensure((size_t)fpart * 8));
-  HIPCHK(ctx, ivf->s_cnt.ensure((size_t)nlist * 4));
-  HIPCHK(ctx, ivf->s_fill.ensure((size_t)nlist * 4));
-  HIPCHK(ctx, ivf->s_eoff.ensure((size_t)(nlist + 1) * 4));
-  HIPCHK(ctx, ivf->s_ioff.ensure((size_t)(nlist + 1) * 4));
-  HIPCHK(ctx, ivf->s_entries.ensure((size_t)B * np * 8));
-  HIPCHK(ctx, ivf->s_scalars.ensure(kScalarsBytes));
-  uint32_t* scal = ivf->s_scalars.as<uint32_t>();
+  HIPCHK(ctx, S.s_qh.ensure((size_t)(B + 1) * ivf->dpad * 2));
+  HIPCHK(ctx, S.s_qn2.ensure((size_t)B * 4));
+  HIPCHK(ctx, S.s_thr.ensure((size_t)B * 4));
+  HIPCHK(ctx, S.s_tA.ensure((size_t)B * 4));
+  HIPCHK(ctx, S.s_pa.ensure((size_t)B * 4));
+  HIPCHK(ctx, S.s_mslots.ensure((size_t)B * 64 * 4));
+  HIPCHK(ctx, S.s_surv.ensure((size_t)B * cmax * 8));
+  HIPCHK(ctx, S.s_sdist.ensure((size_t)B * cmax * 4));
+  HIPCHK(ctx, S.s_scnt.ensure((size_t)(B + 2) * 4));  // [B] survivor counts, then nfail and the rescan queue head
+  HIPCHK(ctx, S.s_fail.ensure((size_t)B * 4));
+  HIPCHK(ctx, S.s_part.ensure((size_t)fpart * 8));
+  HIPCHK(ctx, S.s_cnt.ensure((size_t)nlist * 4));
+  HIPCHK(ctx, S.s_fill.ensure((size_t)nlist * 4));
+  HIPCHK(ctx, S.s_eoff.ensure((size_t)(nlist + 1) * 4));
+  HIPCHK(ctx, S.s_ioff.ensure((size_t)(nlist + 1) * 4));
+  HIPCHK(ctx, S.s_entries.ensure((size_t)B * np * 8));
+  HIPCHK(ctx, S.s_scalars.ensure(kScalarsBytes));
+  uint32_t* scal = S.s_scalars.as<uint32_t>();
   const uint32_t grid = (uint32_t)ctx->num_cus * (uint32_t)std::max(1, wgs_env);
   const ListTable lists{ivf->t_off.as<uint32_t>(), ivf->t_blocks.as<uint32_t>(), nlist};
-  if (ctx->profiling) (void)hipEventRecord(ivf->sev[3], ctx->stream);
+  if (ctx->profiling) (void)hipEventRecord(S.sev[3], ctx->stream);
 
   hipLaunchKernelGGL(prep_queries_kernel, dim3(cdiv(B + 1, 4)), dim3(256), 0, ctx->stream, qpad, B, ivf->dpad,
-                     (_Float16*)ivf->s_qh.p, ivf->s_qn2.as<float>(), ivf->s_cnt.as<uint32_t>(), nlist,
-                     ivf->s_scnt.as<uint32_t>(), ivf->s_mslots.as<uint32_t>());
+                     (_Float16*)S.s_qh.p, S.s_qn2.as<float>(), S.s_cnt.as<uint32_t>(), nlist,
+                     S.s_scnt.as<uint32_t>(), S.s_mslots.as<uint32_t>());
   hipLaunchKernelGGL(first_probe_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, probes, B, np,
-                     ivf->t_len.as<uint32_t>(), 256u, ivf->s_pa.as<uint32_t>());
+                     ivf->t_len.as<uint32_t>(), 256u, S.s_pa.as<uint32_t>());
   auto plan = [&](const uint32_t* pr, uint32_t n, uint32_t npp, uint32_t sb, unsigned long long* stats) {
     // cnt[] is zero on entry: cleared by prep_queries_kernel for the first plan, by plan_scan_kernel for the second
-    hipLaunchKernelGGL(plan_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, pr, n, ivf->s_cnt.as<uint32_t>());
-    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ivf->s_cnt.as<uint32_t>(), lists.off,
-                       ivf->t_len.as<uint32_t>(), nlist, sb, Q, ivf->s_eoff.as<uint32_t>(), ivf->s_ioff.as<uint32_t>(),
-                       ivf->s_fill.as<uint32_t>(), scal + 2, scal + 3, stats, ivf->s_cnt.as<uint32_t>());
+    hipLaunchKernelGGL(plan_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, pr, n, S.s_cnt.as<uint32_t>());
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, S.s_cnt.as<uint32_t>(), lists.off,
+                       ivf->t_len.as<uint32_t>(), nlist, sb, Q, S.s_eoff.as<uint32_t>(), S.s_ioff.as<uint32_t>(),
+                       S.s_fill.as<uint32_t>(), scal + 2, scal + 3, stats, S.s_cnt.as<uint32_t>());
     hipLaunchKernelGGL(plan_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, pr, n, npp,
-                       ivf->s_eoff.as<uint32_t>(), ivf->s_fill.as<uint32_t>(), ivf->s_entries.as<uint2>());
+                       S.s_eoff.as<uint32_t>(), S.s_fill.as<uint32_t>(), S.s_entries.as<uint2>());
   };
   MfmaScanArgs a{};
   const bool half_rows = ivf->f16 || ivf->pool.half != nullptr;  // the filter reads fp16 rows (stored or mirrored)
@@ -599,38 +635,38 @@ int run_fine_mfma(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint
   a.list_off = lists.off;
   a.list_blocks = lists.blocks;
   a.nlist = nlist;
-  a.entry_off = ivf->s_eoff.as<uint32_t>();
-  a.item_off = ivf->s_ioff.as<uint32_t>();
-  a.entries = (const u32x2*)ivf->s_entries.p;
+  a.entry_off = S.s_eoff.as<uint32_t>();
+  a.item_off = S.s_ioff.as<uint32_t>();
+  a.entries = (const u32x2*)S.s_entries.p;
   a.n_items = scal + 2;
   a.head = scal + 3;
-  a.qh = (const _Float16*)ivf->s_qh.p;
+  a.qh = (const _Float16*)S.s_qh.p;
   a.zero_row = B;
   a.dpad = ivf->dpad;
-  a.thr = ivf->s_thr.as<float>();
+  a.thr = S.s_thr.as<float>();
   a.cmax = cmax;
-  a.surv = (u32x2*)ivf->s_surv.p;
-  a.sval = ivf->s_sdist.as<float>();
-  a.scnt = ivf->s_scnt.as<uint32_t>();
-  a.slots = ivf->s_mslots.as<uint32_t>();
+  a.surv = (u32x2*)S.s_surv.p;
+  a.sval = S.s_sdist.as<float>();
+  a.scnt = S.s_scnt.as<uint32_t>();
+  a.slots = S.s_mslots.as<uint32_t>();
   a.capA = (uint32_t)std::max(1, capA_env);
 
   // A. threshold: MFMA pass over the first segment of a near list -> (k+6)-th smallest v -> thr
-  plan(ivf->s_pa.as<uint32_t>(), B, 1, segbA, nullptr);
+  plan(S.s_pa.as<uint32_t>(), B, 1, segbA, nullptr);
   a.segb = segbA;
   launch_mfma<1>(ctx, a, M, half_rows, grid);
-  hipLaunchKernelGGL(threshold_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, ivf->s_mslots.as<uint32_t>(),
-                     ivf->s_pa.as<uint32_t>(), ivf->s_qn2.as<float>(), ivf->d_xmax.as<uint32_t>(), B, ka, ivf->dpad,
-                     x_rounded, ivf->s_thr.as<float>());
+  hipLaunchKernelGGL(threshold_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, S.s_mslots.as<uint32_t>(),
+                     S.s_pa.as<uint32_t>(), S.s_qn2.as<float>(), ivf->d_xmax.as<uint32_t>(), B, ka, ivf->dpad,
+                     x_rounded, S.s_thr.as<float>());
 
   // B. filter over all probed lists
   plan(probes, B * np, np, segb, (unsigned long long*)(scal + 4));
   a.segb = segb;
-  if (ctx->profiling) (void)hipEventRecord(ivf->sev[6], ctx->stream);
+  if (ctx->profiling) (void)hipEventRecord(S.sev[6], ctx->stream);
   launch_mfma<0>(ctx, a, M, half_rows, grid);
-  if (ctx->profiling) (void)hipEventRecord(ivf->sev[7], ctx->stream);
-  if (ctx->profiling) (void)hipEventRecord(ivf->sev[4], ctx->stream);
-  ivf->pend_filter = true;
+  if (ctx->profiling) (void)hipEventRecord(S.sev[7], ctx->stream);
+  if (ctx->profiling) (void)hipEventRecord(S.sev[4], ctx->stream);
+  S.pend_filter = true;
 
   // C. select
   VerifyArgs v{};
@@ -639,12 +675,12 @@ int run_fine_mfma(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint
   v.probes = probes;
   v.glob_blocks = ivf->t_glob.as<uint32_t>();
   v.queries = qpad;
-  v.qn = ivf->s_qn2.as<float>();
+  v.qn = S.s_qn2.as<float>();
   v.xmax_bits = ivf->d_xmax.as<uint32_t>();
-  v.thr = ivf->s_thr.as<float>();
-  v.surv = (const u32x2*)ivf->s_surv.p;
-  v.sval = ivf->s_sdist.as<float>();
-  v.scnt = ivf->s_scnt.as<uint32_t>();
+  v.thr = S.s_thr.as<float>();
+  v.surv = (const u32x2*)S.s_surv.p;
+  v.sval = S.s_sdist.as<float>();
+  v.scnt = S.s_scnt.as<uint32_t>();
   v.B = B;
   v.k = k;
   v.ka = ka;
@@ -658,8 +694,8 @@ int run_fine_mfma(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint
   v.out_counts = out_counts;
   v.out_keys = out_keys;
   v.fallbacks = ivf->s_fallbacks.as<uint32_t>() + 1;
-  v.fail_list = ivf->s_fail.as<uint32_t>();
-  v.nfail = ivf->s_scnt.as<uint32_t>() + B;
+  v.fail_list = S.s_fail.as<uint32_t>();
+  v.nfail = S.s_scnt.as<uint32_t>() + B;
   if (ivf->f16) hipLaunchKernelGGL((select_kernel<1>), dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, v);
   else hipLaunchKernelGGL((select_kernel<0>), dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, v);
 
@@ -671,13 +707,13 @@ int run_fine_mfma(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint
   fa.queries = qpad;
   fa.fail_list = v.fail_list;
   fa.nfail = v.nfail;
-  fa.head = ivf->s_scnt.as<uint32_t>() + B + 1;
+  fa.head = S.s_scnt.as<uint32_t>() + B + 1;
   fa.k = k;
   fa.nprobe = np;
   fa.dpad = ivf->dpad;
   fa.segb = fsegb;
   fa.maxsegs = fmaxsegs;
-  fa.part = (u32x2*)ivf->s_part.p;
+  fa.part = (u32x2*)S.s_part.p;
   if (ivf->f16) hipLaunchKernelGGL((fallback_scan_kernel<1>), dim3(grid), dim3(256), 0, ctx->stream, fa);
   else hipLaunchKernelGGL((fallback_scan_kernel<0>), dim3(grid), dim3(256), 0, ctx->stream, fa);
   MergeArgs fm{};
@@ -685,7 +721,7 @@ int run_fine_mfma(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint
   fm.lists = lists;
   fm.probes = probes;
   fm.glob_blocks = ivf->t_glob.as<uint32_t>();
-  fm.part = ivf->s_part.as<uint2>();
+  fm.part = S.s_part.as<uint2>();
   fm.B = B;
   fm.k = k;
   fm.nprobe = np;
@@ -698,22 +734,27 @@ int run_fine_mfma(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint
   fm.qlist = v.fail_list;
   fm.nq = v.nfail;
   launch_merge(ctx, fm);
-  if (ctx->profiling) (void)hipEventRecord(ivf->sev[5], ctx->stream);
+  if (ctx->profiling) (void)hipEventRecord(S.sev[5], ctx->stream);
   // the rescan counter, for AUTO's hit-rate watch (run_fine): a 4-byte copy into pinned memory, nobody waits for it
-  HIPCHK(ctx, ivf->h_fb.ensure(64));
+  {
+    std::lock_guard<std::mutex> lk(ivf->mu);
+    HIPCHK(ctx, ivf->h_fb.ensure(64));
+    ivf->mfma_q += B;
+  }
   HIPCHK(ctx, hipMemcpyAsync(ivf->h_fb.p, ivf->s_fallbacks.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-  ivf->mfma_q += B;
   HIPCHK(ctx, hipGetLastError());
   return FVDB_OK;
 }
 
-int run_fine(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t np, const uint32_t* probes,
+int run_fine(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, uint32_t k, uint32_t np, const uint32_t* probes,
              uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys, int role) {
+  IvfScratch& S = *E.S;
   static const bool env_exact = getenv("FVDB_SCAN_EXACT") != nullptr;  // tuning aid
-  ivf->pend_filter = false;
+  S.pend_filter = false;
   bool mfma = ivf->scan_mode == 0 && !env_exact && role == ROLE_LIST && ivf->dpad % 16 == 0 &&
               k + kMfmaSlack <= 32 && np <= 256 && B >= 32 && B <= 16384 && ivf->pool.norms != nullptr;
   if (mfma) {
+    std::lock_guard<std::mutex> lk(ivf->mu);  // the hit-rate watch is shared by every search on the index
     if (ivf->exact_batches_left > 0) {
       ivf->exact_batches_left -= 1;
       mfma = false;
@@ -732,38 +773,39 @@ int run_fine(fvdb_ivf* ivf, const float* qpad, uint32_t B, uint32_t k, uint32_t 
       }
     }
   }
-  if (mfma) return run_fine_mfma(ivf, qpad, B, k, np, probes, out_ids, out_dist, out_counts, out_keys);
-  return run_fine_exact(ivf, qpad, B, k, np, probes, out_ids, out_dist, out_counts, out_keys, role);
+  if (mfma) return run_fine_mfma(ivf, E, qpad, B, k, np, probes, out_ids, out_dist, out_counts, out_keys);
+  return run_fine_exact(ivf, E, qpad, B, k, np, probes, out_ids, out_dist, out_counts, out_keys, role);
 }
 
-int finish_profile(fvdb_ivf* ivf, bool coarse, bool fine) {
-  fvdb_ctx* ctx = ivf->ctx;
+int finish_profile(fvdb_ivf* ivf, const Env& E, bool coarse, bool fine) {
+  fvdb_ctx* ctx = E.ctx;
+  IvfScratch& S = *E.S;
   if (!ctx->profiling) return FVDB_OK;
-  if (ctx->profiling == 2 && !ivf->collecting) {  // deferred: remember what to fold in later
-    ivf->pend_coarse = coarse;
-    ivf->pend_fine = fine;
-    ivf->pending_profile = true;
+  if (ctx->profiling == 2 && !S.collecting) {  // deferred: remember what to fold in later
+    S.pend_coarse = coarse;
+    S.pend_fine = fine;
+    S.pending_profile = true;
     return FVDB_OK;
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   float ms = 0;
   if (coarse) {
-    (void)hipEventElapsedTime(&ms, ivf->sev[0], ivf->sev[1]);
+    (void)hipEventElapsedTime(&ms, S.sev[0], S.sev[1]);
     ivf->stage_ms[0] += ms;
-    (void)hipEventElapsedTime(&ms, ivf->sev[1], ivf->sev[2]);
+    (void)hipEventElapsedTime(&ms, S.sev[1], S.sev[2]);
     ivf->stage_ms[1] += ms;
   }
   if (fine) {
     if (coarse) {
-      (void)hipEventElapsedTime(&ms, ivf->sev[2], ivf->sev[3]);
+      (void)hipEventElapsedTime(&ms, S.sev[2], S.sev[3]);
       ivf->stage_ms[2] += ms;
     }
-    (void)hipEventElapsedTime(&ms, ivf->sev[3], ivf->sev[4]);
+    (void)hipEventElapsedTime(&ms, S.sev[3], S.sev[4]);
     ivf->stage_ms[3] += ms;
-    (void)hipEventElapsedTime(&ms, ivf->sev[4], ivf->sev[5]);
+    (void)hipEventElapsedTime(&ms, S.sev[4], S.sev[5]);
     ivf->stage_ms[4] += ms;
-    if (ivf->pend_filter) {
-      (void)hipEventElapsedTime(&ms, ivf->sev[6], ivf->sev[7]);
+    if (S.pend_filter) {
+      (void)hipEventElapsedTime(&ms, S.sev[6], S.sev[7]);
       ivf->stage_ms[5] += ms;
     }
   }
@@ -834,7 +876,13 @@ int fvdb_ctx_synchronize(fvdb_ctx* ctx) {
   return FVDB_OK;
 }
 void* fvdb_ctx_stream(fvdb_ctx* ctx) { return (void*)ctx->stream; }
-const char* fvdb_last_error(fvdb_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char* fvdb_last_error(fvdb_ctx* ctx) {
+  if (!ctx) return "null context";
+  static thread_local std::string copy;  // another thread's failure must not pull the text from under the reader
+  std::lock_guard<std::mutex> lk(ctx->err_mu);
+  copy = ctx->err;
+  return copy.c_str();
+}
 int fvdb_ctx_set_profiling(fvdb_ctx* ctx, int on) {
   ctx->profiling = on;
   return FVDB_OK;
@@ -1000,6 +1048,9 @@ void fvdb_ivf_destroy(fvdb_ivf* ivf) {
   for (DBuf* b : bufs) b->release();
   ivf->release_all();
   for (auto& sp : ivf->spare) sp.release_all();
+  for (auto& sp : ivf->lease_set) sp.release_all();
+  for (auto& c : ivf->lease_ctx)
+    if (c) fvdb_ctx_destroy(c);
   ivf->h_fb.release();
   delete ivf;
 }
@@ -1159,9 +1210,10 @@ static int assign_dev(fvdb_ivf* ivf, const float* x_dev, uint64_t n, uint32_t* o
   for (uint64_t o = 0; o < n; o += step) {
     const uint32_t B = (uint32_t)std::min<uint64_t>(step, n - o);
     const float* qpad = nullptr;
-    int rc = padded_queries(ivf, x_dev + o * ivf->d, B, &qpad);
+    const Env E{ivf->ctx, ivf};
+    int rc = padded_queries(ivf, E, x_dev + o * ivf->d, B, &qpad);
     if (rc) return rc;
-    rc = run_coarse(ivf, qpad, B, 1, out_dev + o, nullptr);
+    rc = run_coarse(ivf, E, qpad, B, 1, out_dev + o, nullptr);
     if (rc) return rc;
   }
   HIPCHK(ctx, hipGetLastError());
@@ -1290,10 +1342,11 @@ int fvdb_ivf_set_deleted(fvdb_ivf* ivf, const uint32_t* cluster, const uint32_t*
 
 // given_probes (device, [B][min(nprobe, nlist)] cluster ids in probe order): the coarse stage is skipped.
 // probes_only (device, same shape): only the coarse stage runs and its result is copied there.
-static int search_common(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t k, uint32_t nprobe, bool all,
+static int search_common(fvdb_ivf* ivf, const Env& E, const float* q_dev, uint32_t B, uint32_t k, uint32_t nprobe, bool all,
                          uint64_t* out_ids, float* out_dist, uint32_t* out_counts, uint64_t* out_keys,
                          const uint32_t* given_probes = nullptr, uint32_t* probes_only = nullptr) {
-  fvdb_ctx* ctx = ivf->ctx;
+  fvdb_ctx* ctx = E.ctx;
+  IvfScratch& S = *E.S;
   if (!ivf->trained) FAIL(ctx, FVDB_E_NOT_TRAINED, "index not trained");
   if (k == 0 || k > FVDB_MAX_K) FAIL(ctx, FVDB_E_UNSUPPORTED, "k must be in 1..FVDB_MAX_K");
   if (B == 0) return FVDB_OK;
@@ -1303,35 +1356,39 @@ static int search_common(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t
   if (!all && np > FVDB_MAX_K) FAIL(ctx, FVDB_E_UNSUPPORTED, "nprobe above FVDB_MAX_K");
   int rc = upload_table(ivf);
   if (rc) return rc;
+  std::lock_guard<std::mutex> enq(S.enq);  // one search's launches go in as a block
+  if (ctx->profiling)
+    for (auto& e : S.sev)
+      if (!e) (void)hipEventCreate(&e);
   const uint32_t step = sub_batch(ivf, B, k, np);
   for (uint32_t o = 0; o < B; o += step) {
     const uint32_t b = std::min(step, B - o);
     const float* qpad = nullptr;
-    rc = padded_queries(ivf, q_dev + (size_t)o * ivf->d, b, &qpad);
+    rc = padded_queries(ivf, E, q_dev + (size_t)o * ivf->d, b, &qpad);
     if (rc) return rc;
-    HIPCHK(ctx, ivf->s_probes.ensure((size_t)b * np * 4));
-    const uint32_t* probes = ivf->s_probes.as<uint32_t>();
+    HIPCHK(ctx, S.s_probes.ensure((size_t)b * np * 4));
+    const uint32_t* probes = S.s_probes.as<uint32_t>();
     if (all) {
       hipLaunchKernelGGL(probes_all_kernel, dim3(cdiv((uint64_t)b * np, 256)), dim3(256), 0, ctx->stream, b, np,
-                         ivf->s_probes.as<uint32_t>());
-      if (ctx->profiling) (void)hipEventRecord(ivf->sev[2], ctx->stream);
+                         S.s_probes.as<uint32_t>());
+      if (ctx->profiling) (void)hipEventRecord(S.sev[2], ctx->stream);
     } else if (given_probes) {
       probes = given_probes + (size_t)o * np;
       if (ctx->profiling) {  // no coarse stage in this call: zero-length stage intervals
-        (void)hipEventRecord(ivf->sev[0], ctx->stream);
-        (void)hipEventRecord(ivf->sev[1], ctx->stream);
-        (void)hipEventRecord(ivf->sev[2], ctx->stream);
+        (void)hipEventRecord(S.sev[0], ctx->stream);
+        (void)hipEventRecord(S.sev[1], ctx->stream);
+        (void)hipEventRecord(S.sev[2], ctx->stream);
       }
     } else {
-      rc = run_coarse(ivf, qpad, b, np, probes_only ? probes_only + (size_t)o * np : ivf->s_probes.as<uint32_t>(), nullptr);
+      rc = run_coarse(ivf, E, qpad, b, np, probes_only ? probes_only + (size_t)o * np : S.s_probes.as<uint32_t>(), nullptr);
       if (rc) return rc;
     }
     if (probes_only) continue;
-    rc = run_fine(ivf, qpad, b, k, np, probes, out_ids ? out_ids + (size_t)o * k : nullptr,
+    rc = run_fine(ivf, E, qpad, b, k, np, probes, out_ids ? out_ids + (size_t)o * k : nullptr,
                   out_dist ? out_dist + (size_t)o * k : nullptr, out_counts ? out_counts + o : nullptr,
                   out_keys ? out_keys + (size_t)o * k : nullptr, all ? ROLE_ALL : ROLE_LIST);
     if (rc) return rc;
-    rc = finish_profile(ivf, !all, true);
+    rc = finish_profile(ivf, E, !all, true);
     if (rc) return rc;
   }
   return FVDB_OK;
@@ -1339,33 +1396,39 @@ static int search_common(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t
 
 int fvdb_ivf_search_dev(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t k, uint32_t nprobe,
                         uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev, uint64_t* out_keys_dev) {
-  return search_common(ivf, q_dev, B, k, nprobe, false, out_ids_dev, out_dist_dev, out_counts_dev, out_keys_dev);
+  return search_common(ivf, Env{ivf->ctx, ivf}, q_dev, B, k, nprobe, false, out_ids_dev, out_dist_dev, out_counts_dev,
+                       out_keys_dev);
 }
 
-// shared by the slot entry points: run `body` with the slot's scratch set and `on`'s stream standing in
-extern "C++" {
-template <typename F>
-static int with_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, F body) {
+// The explicit-slot entry points: the caller names the scratch set (slot) and the stream (`on`); nothing in the index
+// object changes, so calls on different slots may come from different host threads at the same time.
+static int slot_env(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, Env* E) {
   if (slot >= fvdb_ivf::kSlots) FAIL(ivf->ctx, FVDB_E_INVALID, "slot out of range");
   if (on && on->device != ivf->ctx->device) FAIL(ivf->ctx, FVDB_E_INVALID, "context of another device");
-  IvfScratch& mine = *ivf;
-  fvdb_ctx* home = ivf->ctx;
-  if (slot > 0) std::swap(mine, ivf->spare[slot - 1]);
-  if (on) ivf->ctx = on;
-  const int rc = body();
-  if (rc && on) home->err = on->err;
-  ivf->ctx = home;
-  if (slot > 0) std::swap(mine, ivf->spare[slot - 1]);
+  E->ctx = on ? on : ivf->ctx;
+  E->S = &slot_scratch(ivf, slot);
+  return FVDB_OK;
+}
+static int slot_done(fvdb_ivf* ivf, const Env& E, int rc) {
+  if (rc && E.ctx != ivf->ctx) {  // the failure text is read from the index's own context
+    std::string m;
+    {
+      std::lock_guard<std::mutex> lk(E.ctx->err_mu);
+      m = E.ctx->err;
+    }
+    ivf->ctx->set_err(m);
+  }
   return rc;
 }
-}  // extern "C++"
 
 int fvdb_ivf_coarse_dev_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t nprobe,
                              uint32_t* out_probes_dev) {
   if (!out_probes_dev) FAIL(ivf->ctx, FVDB_E_INVALID, "null output");
-  return with_slot(ivf, on, slot, [&]() {
-    return search_common(ivf, q_dev, B, 1, nprobe, false, nullptr, nullptr, nullptr, nullptr, nullptr, out_probes_dev);
-  });
+  Env E{};
+  int rc = slot_env(ivf, on, slot, &E);
+  if (rc) return rc;
+  return slot_done(ivf, E, search_common(ivf, E, q_dev, B, 1, nprobe, false, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                         out_probes_dev));
 }
 
 int fvdb_ivf_search_probes_dev_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev,
@@ -1373,49 +1436,99 @@ int fvdb_ivf_search_probes_dev_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, 
                                     uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev,
                                     uint64_t* out_keys_dev) {
   if (!probes_dev) FAIL(ivf->ctx, FVDB_E_INVALID, "null probes");
-  return with_slot(ivf, on, slot, [&]() {
-    return search_common(ivf, q_dev, B, k, nprobe, false, out_ids_dev, out_dist_dev, out_counts_dev, out_keys_dev, probes_dev);
-  });
+  Env E{};
+  int rc = slot_env(ivf, on, slot, &E);
+  if (rc) return rc;
+  return slot_done(ivf, E, search_common(ivf, E, q_dev, B, k, nprobe, false, out_ids_dev, out_dist_dev, out_counts_dev,
+                                         out_keys_dev, probes_dev));
 }
 
 int fvdb_ivf_search_dev_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t k,
                              uint32_t nprobe, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev,
                              uint64_t* out_keys_dev) {
-  // the slot's scratch set and stream stand in for the index's own for the duration of the call: every launch
-  // goes to `on`'s stream and touches only this slot's scratch, so slots can be in flight together
-  return with_slot(ivf, on, slot, [&]() {
-    return search_common(ivf, q_dev, B, k, nprobe, false, out_ids_dev, out_dist_dev, out_counts_dev, out_keys_dev);
-  });
+  // every launch goes to `on`'s stream and touches only this slot's scratch, so slots can be in flight together
+  Env E{};
+  int rc = slot_env(ivf, on, slot, &E);
+  if (rc) return rc;
+  return slot_done(ivf, E, search_common(ivf, E, q_dev, B, k, nprobe, false, out_ids_dev, out_dist_dev, out_counts_dev,
+                                         out_keys_dev));
 }
 
 int fvdb_ivf_search_all_dev(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t k, uint64_t* out_ids_dev,
                             float* out_dist_dev, uint32_t* out_counts_dev) {
-  return search_common(ivf, q_dev, B, k, 0, true, out_ids_dev, out_dist_dev, out_counts_dev, nullptr);
+  return search_common(ivf, Env{ivf->ctx, ivf}, q_dev, B, k, 0, true, out_ids_dev, out_dist_dev, out_counts_dev, nullptr);
 }
+
+// A leased scratch set + stream for one blocking search: any number of host threads may call the host-pointer
+// entry points on one index; each call takes a free set (or waits for one) and gives it back when it returns.
+// With stage profiling on, the call runs on the index's own stream with set 0 instead (a measuring run is one thread).
+extern "C++" {
+namespace {
+struct Lease {
+  fvdb_ivf* ivf;
+  int idx = -1;
+  Env E{};
+  int rc = FVDB_OK;
+  explicit Lease(fvdb_ivf* ivf_) : ivf(ivf_) {
+    if (ivf->ctx->profiling) {
+      E = Env{ivf->ctx, ivf};
+      return;
+    }
+    std::unique_lock<std::mutex> lk(ivf->mu);
+    ivf->lease_cv.wait(lk, [&] { return ivf->lease_busy != (1u << fvdb_ivf::kLeases) - 1u; });
+    for (uint32_t i = 0; i < fvdb_ivf::kLeases; ++i)
+      if (!(ivf->lease_busy & (1u << i))) {
+        idx = (int)i;
+        break;
+      }
+    ivf->lease_busy |= 1u << idx;
+    if (!ivf->lease_ctx[idx]) {
+      rc = fvdb_ctx_create(ivf->ctx->device, &ivf->lease_ctx[idx]);
+      if (rc) ivf->ctx->set_err("could not create a stream for a concurrent search");
+    }
+    E = Env{ivf->lease_ctx[idx], &ivf->lease_set[idx]};
+  }
+  ~Lease() {
+    if (idx < 0) return;
+    {
+      std::lock_guard<std::mutex> lk(ivf->mu);
+      ivf->lease_busy &= ~(1u << idx);
+    }
+    ivf->lease_cv.notify_one();
+  }
+};
+}  // namespace
+}  // extern "C++"
 
 static int search_host(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t k, uint32_t nprobe, bool all,
                        uint64_t* out_ids, float* out_dist, uint32_t* out_counts) {
-  fvdb_ctx* ctx = ivf->ctx;
-  if (!ivf->trained) FAIL(ctx, FVDB_E_NOT_TRAINED, "index not trained");
+  if (!ivf->trained) FAIL(ivf->ctx, FVDB_E_NOT_TRAINED, "index not trained");
   if (B == 0) return FVDB_OK;
-  if (k == 0 || k > FVDB_MAX_K) FAIL(ctx, FVDB_E_UNSUPPORTED, "k must be in 1..FVDB_MAX_K");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  int rc = check_finite(ctx, q, (uint64_t)B * ivf->d);
+  if (k == 0 || k > FVDB_MAX_K) FAIL(ivf->ctx, FVDB_E_UNSUPPORTED, "k must be in 1..FVDB_MAX_K");
+  int rc = check_finite(ivf->ctx, q, (uint64_t)B * ivf->d);
   if (rc) return rc;
-  HIPCHK(ctx, ivf->s_in.ensure((size_t)B * ivf->d * 4));
-  HIPCHK(ctx, ivf->s_out_ids.ensure((size_t)B * k * 8));
-  HIPCHK(ctx, ivf->s_out_dist.ensure((size_t)B * k * 4));
-  HIPCHK(ctx, ivf->s_out_cnt.ensure((size_t)B * 4));
-  HIPCHK(ctx, hipMemcpyAsync(ivf->s_in.p, q, (size_t)B * ivf->d * 4, hipMemcpyHostToDevice, ctx->stream));
-  rc = search_common(ivf, ivf->s_in.as<float>(), B, k, nprobe, all, ivf->s_out_ids.as<uint64_t>(),
-                     ivf->s_out_dist.as<float>(), ivf->s_out_cnt.as<uint32_t>(), nullptr);
-  if (rc) return rc;
-  HIPCHK(ctx, hipMemcpyAsync(out_ids, ivf->s_out_ids.p, (size_t)B * k * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(out_dist, ivf->s_out_dist.p, (size_t)B * k * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (out_counts)
-    HIPCHK(ctx, hipMemcpyAsync(out_counts, ivf->s_out_cnt.p, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return FVDB_OK;
+  Lease L(ivf);
+  if (L.rc) return L.rc;
+  fvdb_ctx* ctx = L.E.ctx;
+  IvfScratch& S = *L.E.S;
+  auto run = [&]() -> int {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, S.s_in.ensure((size_t)B * ivf->d * 4));
+    HIPCHK(ctx, S.s_out_ids.ensure((size_t)B * k * 8));
+    HIPCHK(ctx, S.s_out_dist.ensure((size_t)B * k * 4));
+    HIPCHK(ctx, S.s_out_cnt.ensure((size_t)B * 4));
+    HIPCHK(ctx, hipMemcpyAsync(S.s_in.p, q, (size_t)B * ivf->d * 4, hipMemcpyHostToDevice, ctx->stream));
+    int r = search_common(ivf, L.E, S.s_in.as<float>(), B, k, nprobe, all, S.s_out_ids.as<uint64_t>(),
+                          S.s_out_dist.as<float>(), S.s_out_cnt.as<uint32_t>(), nullptr);
+    if (r) return r;
+    HIPCHK(ctx, hipMemcpyAsync(out_ids, S.s_out_ids.p, (size_t)B * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out_dist, S.s_out_dist.p, (size_t)B * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_counts)
+      HIPCHK(ctx, hipMemcpyAsync(out_counts, S.s_out_cnt.p, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FVDB_OK;
+  };
+  return slot_done(ivf, L.E, run());
 }
 
 int fvdb_ivf_search(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t k, uint32_t nprobe, uint64_t* out_ids,
@@ -1429,28 +1542,38 @@ int fvdb_ivf_search_all(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t k, u
 
 int fvdb_ivf_coarse(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t nprobe, uint32_t* out_clusters,
                     float* out_dist) {
-  fvdb_ctx* ctx = ivf->ctx;
-  if (!ivf->trained) FAIL(ctx, FVDB_E_NOT_TRAINED, "index not trained");
+  if (!ivf->trained) FAIL(ivf->ctx, FVDB_E_NOT_TRAINED, "index not trained");
   if (B == 0) return FVDB_OK;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   const uint32_t np = std::min(nprobe, ivf->nlist);
-  if (np == 0 || np > FVDB_MAX_K) FAIL(ctx, FVDB_E_UNSUPPORTED, "nprobe must be in 1..FVDB_MAX_K");
-  int rc = check_finite(ctx, q, (uint64_t)B * ivf->d);
+  if (np == 0 || np > FVDB_MAX_K) FAIL(ivf->ctx, FVDB_E_UNSUPPORTED, "nprobe must be in 1..FVDB_MAX_K");
+  int rc = check_finite(ivf->ctx, q, (uint64_t)B * ivf->d);
   if (rc) return rc;
-  HIPCHK(ctx, ivf->s_in.ensure((size_t)B * ivf->d * 4));
-  HIPCHK(ctx, ivf->s_probes.ensure((size_t)B * np * 4));
-  HIPCHK(ctx, ivf->s_cdist.ensure((size_t)B * np * 4));
-  HIPCHK(ctx, hipMemcpyAsync(ivf->s_in.p, q, (size_t)B * ivf->d * 4, hipMemcpyHostToDevice, ctx->stream));
-  const float* qpad = nullptr;
-  rc = padded_queries(ivf, ivf->s_in.as<float>(), B, &qpad);
-  if (rc) return rc;
-  rc = run_coarse(ivf, qpad, B, np, ivf->s_probes.as<uint32_t>(), ivf->s_cdist.as<float>());
-  if (rc) return rc;
-  HIPCHK(ctx, hipMemcpyAsync(out_clusters, ivf->s_probes.p, (size_t)B * np * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (out_dist)
-    HIPCHK(ctx, hipMemcpyAsync(out_dist, ivf->s_cdist.p, (size_t)B * np * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return FVDB_OK;
+  Lease L(ivf);
+  if (L.rc) return L.rc;
+  fvdb_ctx* ctx = L.E.ctx;
+  IvfScratch& S = *L.E.S;
+  auto run = [&]() -> int {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> enq(S.enq);
+    HIPCHK(ctx, S.s_in.ensure((size_t)B * ivf->d * 4));
+    HIPCHK(ctx, S.s_probes.ensure((size_t)B * np * 4));
+    HIPCHK(ctx, S.s_cdist.ensure((size_t)B * np * 4));
+    HIPCHK(ctx, hipMemcpyAsync(S.s_in.p, q, (size_t)B * ivf->d * 4, hipMemcpyHostToDevice, ctx->stream));
+    const float* qpad = nullptr;
+    int r = padded_queries(ivf, L.E, S.s_in.as<float>(), B, &qpad);
+    if (r) return r;
+    if (ctx->profiling)
+      for (auto& e : S.sev)
+        if (!e) (void)hipEventCreate(&e);
+    r = run_coarse(ivf, L.E, qpad, B, np, S.s_probes.as<uint32_t>(), S.s_cdist.as<float>());
+    if (r) return r;
+    HIPCHK(ctx, hipMemcpyAsync(out_clusters, S.s_probes.p, (size_t)B * np * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_dist)
+      HIPCHK(ctx, hipMemcpyAsync(out_dist, S.s_cdist.p, (size_t)B * np * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FVDB_OK;
+  };
+  return slot_done(ivf, L.E, run());
 }
 
 int fvdb_ivf_set_coarse_mode(fvdb_ivf* ivf, int mode) {
@@ -1545,7 +1668,7 @@ int fvdb_ivf_last_stats(fvdb_ivf* ivf, fvdb_search_stats* out) {
 int fvdb_ivf_profile_collect(fvdb_ivf* ivf) {
   if (!ivf->pending_profile) return FVDB_OK;
   ivf->collecting = true;
-  int rc = finish_profile(ivf, ivf->pend_coarse, ivf->pend_fine);
+  int rc = finish_profile(ivf, Env{ivf->ctx, ivf}, ivf->pend_coarse, ivf->pend_fine);
   ivf->collecting = false;
   ivf->pending_profile = false;
   return rc;
@@ -1584,7 +1707,7 @@ int fvdb_ivf_train(fvdb_ivf* ivf, const float* x, uint64_t n, uint32_t max_itera
   do {                                                                    \
     hipError_t e_ = (call);                                               \
     if (e_ != hipSuccess) {                                               \
-      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);       \
+      ctx->set_err(std::string(#call) + ": " + hipGetErrorString(e_));    \
       cleanup();                                                          \
       return e_ == hipErrorOutOfMemory ? FVDB_E_OOM : FVDB_E_HIP;         \
     }                                                                     \
@@ -1719,6 +1842,157 @@ int fvdb_merge_keys_dev(fvdb_ctx* ctx, const uint64_t* keys, const uint64_t* ids
   }
   HIPCHK(ctx, hipGetLastError());
   return FVDB_OK;
+}
+
+// =============================================================================================
+// top-k / merge utilities (a4): src/core/vector_ops.rs:12-32,180-263, src/core/types.rs:206-223
+// =============================================================================================
+static int check_no_nan(fvdb_ctx* ctx, const float* x, uint64_t n) {
+  for (uint64_t i = 0; i < n; ++i)
+    if (x[i] != x[i]) FAIL(ctx, FVDB_E_NONFINITE, "NaN score (the reference panics in partial_cmp().unwrap())");
+  return FVDB_OK;
+}
+
+int fvdb_top_k_indices_dev(fvdb_ctx* ctx, const float* scores_dev, uint32_t B, uint64_t n, uint32_t k, int heap,
+                           uint64_t* out_idx_dev, uint32_t* out_counts_dev) {
+  if (!ctx || !out_idx_dev || !out_counts_dev) return FVDB_E_INVALID;
+  if (k > FVDB_MAX_K) FAIL(ctx, FVDB_E_UNSUPPORTED, "k above FVDB_MAX_K");
+  if (n >= 0xFFFFFFFFull) FAIL(ctx, FVDB_E_UNSUPPORTED, "rows longer than 2^32-2 scores");
+  if (B == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (k == 0) {  // :181-183 `if k == 0 { return vec![] }`; take(0)
+    HIPCHK(ctx, hipMemsetAsync(out_counts_dev, 0, (size_t)B * 4, ctx->stream));
+    return FVDB_OK;
+  }
+  if (heap) {
+    const size_t lds = (size_t)(k + 64) * sizeof(UItem) + 16;
+    hipLaunchKernelGGL((topk_heap_kernel<false>), dim3(B), dim3(64), lds, ctx->stream, scores_dev, (const uint64_t*)nullptr, B,
+                       (uint32_t)n, k, out_idx_dev, (float*)nullptr, out_counts_dev);
+  } else {
+    const uint32_t grid = cdiv(B, 4);
+    switch (kr_for(k)) {
+      case 1: hipLaunchKernelGGL((topk_sort_kernel<1>), dim3(grid), dim3(256), 0, ctx->stream, scores_dev, B, (uint32_t)n, k, out_idx_dev, out_counts_dev); break;
+      case 2: hipLaunchKernelGGL((topk_sort_kernel<2>), dim3(grid), dim3(256), 0, ctx->stream, scores_dev, B, (uint32_t)n, k, out_idx_dev, out_counts_dev); break;
+      default: hipLaunchKernelGGL((topk_sort_kernel<4>), dim3(grid), dim3(256), 0, ctx->stream, scores_dev, B, (uint32_t)n, k, out_idx_dev, out_counts_dev); break;
+    }
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return FVDB_OK;
+}
+
+int fvdb_streaming_top_k_dev(fvdb_ctx* ctx, const uint64_t* ids_dev, const float* scores_dev, uint32_t B, uint64_t n,
+                             uint32_t k, uint64_t* out_ids_dev, float* out_scores_dev, uint32_t* out_counts_dev) {
+  if (!ctx || !out_ids_dev || !out_counts_dev) return FVDB_E_INVALID;
+  if (k > FVDB_MAX_K) FAIL(ctx, FVDB_E_UNSUPPORTED, "k above FVDB_MAX_K");
+  if (n >= 0xFFFFFFFFull) FAIL(ctx, FVDB_E_UNSUPPORTED, "rows longer than 2^32-2 scores");
+  if (B == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (k == 0) {
+    HIPCHK(ctx, hipMemsetAsync(out_counts_dev, 0, (size_t)B * 4, ctx->stream));
+    return FVDB_OK;
+  }
+  const size_t lds = (size_t)(k + 64) * sizeof(UItem) + 16;
+  hipLaunchKernelGGL((topk_heap_kernel<true>), dim3(B), dim3(64), lds, ctx->stream, scores_dev, ids_dev, B, (uint32_t)n, k,
+                     out_ids_dev, out_scores_dev, out_counts_dev);
+  HIPCHK(ctx, hipGetLastError());
+  return FVDB_OK;
+}
+
+int fvdb_merge_search_results_dev(fvdb_ctx* ctx, const uint64_t* ids_dev, const float* dist_dev, uint32_t B, uint64_t n,
+                                  uint32_t k, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev) {
+  if (!ctx || !out_ids_dev || !out_dist_dev || !out_counts_dev) return FVDB_E_INVALID;
+  if (k > FVDB_MAX_K) FAIL(ctx, FVDB_E_UNSUPPORTED, "k above FVDB_MAX_K");
+  if (n >= (1ull << 20)) FAIL(ctx, FVDB_E_UNSUPPORTED, "more than 2^20 results per query");
+  if (B == 0) return FVDB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (k == 0) {
+    HIPCHK(ctx, hipMemsetAsync(out_counts_dev, 0, (size_t)B * 4, ctx->stream));
+    return FVDB_OK;
+  }
+  const uint32_t grid = cdiv(B, 4);
+  switch (kr_for(k)) {
+    case 1: hipLaunchKernelGGL((merge_dedup_kernel<1>), dim3(grid), dim3(256), 0, ctx->stream, ids_dev, dist_dev, B, (uint32_t)n, k, out_ids_dev, out_dist_dev, out_counts_dev); break;
+    case 2: hipLaunchKernelGGL((merge_dedup_kernel<2>), dim3(grid), dim3(256), 0, ctx->stream, ids_dev, dist_dev, B, (uint32_t)n, k, out_ids_dev, out_dist_dev, out_counts_dev); break;
+    default: hipLaunchKernelGGL((merge_dedup_kernel<4>), dim3(grid), dim3(256), 0, ctx->stream, ids_dev, dist_dev, B, (uint32_t)n, k, out_ids_dev, out_dist_dev, out_counts_dev); break;
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return FVDB_OK;
+}
+
+// host-pointer forms: stage, run the device form, copy back
+namespace {
+struct UtilBufs {
+  void *a = nullptr, *b = nullptr, *o1 = nullptr, *o2 = nullptr, *oc = nullptr;
+  ~UtilBufs() {
+    for (void* p : {a, b, o1, o2, oc})
+      if (p) (void)hipFree(p);
+  }
+};
+}  // namespace
+
+static int top_k_host(fvdb_ctx* ctx, const float* scores, uint32_t B, uint64_t n, uint32_t k, int heap, uint64_t* out_idx,
+                      uint32_t* out_counts) {
+  if (!ctx || !scores || !out_counts || (!out_idx && k)) return FVDB_E_INVALID;
+  if (B == 0) return FVDB_OK;
+  int rc = check_no_nan(ctx, scores, (uint64_t)B * n);
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  UtilBufs u;
+  HIPCHK(ctx, hipMalloc(&u.a, std::max<size_t>((size_t)B * n * 4, 16)));
+  HIPCHK(ctx, hipMalloc(&u.o1, std::max<size_t>((size_t)B * k * 8, 16)));
+  HIPCHK(ctx, hipMalloc(&u.oc, (size_t)B * 4));
+  HIPCHK(ctx, hipMemcpyAsync(u.a, scores, (size_t)B * n * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = fvdb_top_k_indices_dev(ctx, (const float*)u.a, B, n, k, heap, (uint64_t*)u.o1, (uint32_t*)u.oc);
+  if (rc) return rc;
+  if (k) HIPCHK(ctx, hipMemcpyAsync(out_idx, u.o1, (size_t)B * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out_counts, u.oc, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+int fvdb_top_k_indices(fvdb_ctx* ctx, const float* scores, uint32_t B, uint64_t n, uint32_t k, uint64_t* out_idx,
+                       uint32_t* out_counts) {
+  return top_k_host(ctx, scores, B, n, k, 0, out_idx, out_counts);
+}
+int fvdb_top_k_indices_heap(fvdb_ctx* ctx, const float* scores, uint32_t B, uint64_t n, uint32_t k, uint64_t* out_idx,
+                            uint32_t* out_counts) {
+  return top_k_host(ctx, scores, B, n, k, 1, out_idx, out_counts);
+}
+
+static int pairs_host(fvdb_ctx* ctx, const uint64_t* ids, const float* vals, uint32_t B, uint64_t n, uint32_t k, int merge,
+                      uint64_t* out_ids, float* out_vals, uint32_t* out_counts) {
+  if (!ctx || !ids || !vals || !out_counts || ((!out_ids || !out_vals) && k)) return FVDB_E_INVALID;
+  if (B == 0) return FVDB_OK;
+  int rc = check_no_nan(ctx, vals, (uint64_t)B * n);
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  UtilBufs u;
+  HIPCHK(ctx, hipMalloc(&u.a, std::max<size_t>((size_t)B * n * 8, 16)));
+  HIPCHK(ctx, hipMalloc(&u.b, std::max<size_t>((size_t)B * n * 4, 16)));
+  HIPCHK(ctx, hipMalloc(&u.o1, std::max<size_t>((size_t)B * k * 8, 16)));
+  HIPCHK(ctx, hipMalloc(&u.o2, std::max<size_t>((size_t)B * k * 4, 16)));
+  HIPCHK(ctx, hipMalloc(&u.oc, (size_t)B * 4));
+  HIPCHK(ctx, hipMemcpyAsync(u.a, ids, (size_t)B * n * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(u.b, vals, (size_t)B * n * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = merge ? fvdb_merge_search_results_dev(ctx, (const uint64_t*)u.a, (const float*)u.b, B, n, k, (uint64_t*)u.o1,
+                                             (float*)u.o2, (uint32_t*)u.oc)
+             : fvdb_streaming_top_k_dev(ctx, (const uint64_t*)u.a, (const float*)u.b, B, n, k, (uint64_t*)u.o1,
+                                        (float*)u.o2, (uint32_t*)u.oc);
+  if (rc) return rc;
+  if (k) {
+    HIPCHK(ctx, hipMemcpyAsync(out_ids, u.o1, (size_t)B * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out_vals, u.o2, (size_t)B * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(ctx, hipMemcpyAsync(out_counts, u.oc, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FVDB_OK;
+}
+int fvdb_streaming_top_k(fvdb_ctx* ctx, const uint64_t* ids, const float* scores, uint32_t B, uint64_t n, uint32_t k,
+                         uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
+  return pairs_host(ctx, ids, scores, B, n, k, 0, out_ids, out_scores, out_counts);
+}
+int fvdb_merge_search_results(fvdb_ctx* ctx, const uint64_t* ids, const float* dist, uint32_t B, uint64_t n, uint32_t k,
+                              uint64_t* out_ids, float* out_dist, uint32_t* out_counts) {
+  return pairs_host(ctx, ids, dist, B, n, k, 1, out_ids, out_dist, out_counts);
 }
 
 // =============================================================================================
@@ -2061,6 +2335,7 @@ int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const
   if (k == 0 || ef == 0 || ef > 4096) FAIL(ctx, FVDB_E_UNSUPPORTED, "ef must be in 1..4096");
   if (B == 0) return FVDB_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> lk(g->mu);
   const float* qd = q_dev;
   if (s->d != s->dpad) {
     HIPCHK(ctx, g->s_q.ensure((size_t)B * s->dpad * 4));

@@ -430,10 +430,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 3))) void
       if (layer == 0 || g.level[node] >= layer) {
         uint32_t cnt, nb = 0;
         if (layer == 0) {  // count and neighbours arrive with one load
+          // lane i holds neighbour i (two independent loads, so a list of 64 neighbours fits the 64 lanes)
           const uint32_t* row = g.adj0 + (size_t)node * g.stride0;
-          const uint32_t w = (uint32_t)lane < g.stride0 ? row[lane] : 0u;
+          const uint32_t w = row[0];
+          nb = (uint32_t)lane + 1 < g.stride0 ? row[lane + 1] : 0u;
           cnt = __builtin_amdgcn_readfirstlane(w);
-          nb = __shfl_down(w, 1);  // lane i holds neighbour i
         } else {
           const uint32_t s = g.slot_of[node] + layer;
           const uint32_t a0 = g.slot_start[s];

@@ -164,6 +164,63 @@ def batch_cosine_similarity(ctx, q, x):
     return _pairwise(ctx, ctx.lib.fvdb_cosine_similarities, q, x)
 
 
+def _score_rows(scores):
+    s = _f32(scores)
+    return s.reshape(1, -1) if s.ndim == 1 else s
+
+
+def _top_k(ctx, fn, scores, k):
+    s = _score_rows(scores)
+    B, n = s.shape
+    out = np.full((B, max(k, 1)), 2**64 - 1, np.uint64)
+    cnt = np.zeros(B, np.uint32)
+    ctx.check(fn(ctx.h, _ptr(s, f32p), B, n, k, _ptr(out, u64p), _ptr(cnt, u32p)))
+    rows = [out[b, : cnt[b]].astype(np.int64).tolist() for b in range(B)]
+    return rows[0] if np.ndim(scores) == 1 else rows
+
+
+def top_k_indices(ctx, scores, k):
+    """top_k_indices (src/core/vector_ops.rs:12-22): indices of the k largest scores, ties in index order.  `scores`
+    is one row or a batch of rows (B x n); a batch returns one list per row."""
+    return _top_k(ctx, ctx.lib.fvdb_top_k_indices, scores, k)
+
+
+def top_k_indices_heap(ctx, scores, k):
+    """top_k_indices_heap (src/core/vector_ops.rs:180-201), the size-k BinaryHeap variant with its exact tie behaviour."""
+    return _top_k(ctx, ctx.lib.fvdb_top_k_indices_heap, scores, k)
+
+
+def _pairs(ctx, fn, ids, vals, k):
+    ids = np.ascontiguousarray(ids, np.uint64)
+    v = _f32(vals)
+    single = v.ndim == 1
+    if single:
+        ids, v = ids.reshape(1, -1), v.reshape(1, -1)
+    B, n = v.shape
+    oi = np.full((B, max(k, 1)), 2**64 - 1, np.uint64)
+    ov = np.zeros((B, max(k, 1)), np.float32)
+    cnt = np.zeros(B, np.uint32)
+    ctx.check(fn(ctx.h, _ptr(ids, u64p), _ptr(v, f32p), B, n, k, _ptr(oi, u64p), _ptr(ov, f32p), _ptr(cnt, u32p)))
+    rows = [[(int(oi[b, i]), float(ov[b, i])) for i in range(cnt[b])] for b in range(B)]
+    return rows[0] if single else rows
+
+
+def streaming_top_k(ctx, ids, scores, k):
+    """StreamingTopK (src/core/vector_ops.rs:204-263): add every (id, score) in order, then get_results() ->
+    [(id, score)] by descending score."""
+    return _pairs(ctx, ctx.lib.fvdb_streaming_top_k, ids, scores, k)
+
+
+def merge_search_results(ctx, result_sets, k):
+    """merge_search_results (src/core/vector_ops.rs:24-32): concatenate the result sets [(id, distance), ...], keep each
+    id's smallest distance (SearchResult::deduplicate, src/core/types.rs:206-223), ascending, first k."""
+    ids = np.array([r[0] for rs in result_sets for r in rs], np.uint64)
+    ds = np.array([r[1] for rs in result_sets for r in rs], np.float32)
+    if ids.size == 0:
+        return []
+    return _pairs(ctx, ctx.lib.fvdb_merge_search_results, ids, ds, k)
+
+
 class DeviceIVF:
     """IVF-flat index resident in HBM (fvdb_ivf): centroids + paged inverted lists."""
 

@@ -172,6 +172,13 @@ int fvh_hybrid_search(void* p, const float* q, uint32_t B, uint32_t d, uint64_t 
   c.historical_k = historical_k;
   return ((HybridIndex*)p)->search(q, B, d, c, now, ids, dist, counts);
 }
+// search_with_filter (src/hybrid/core.rs:513-549): `matches(id, user)` is the host application's metadata lookup +
+// MetadataFilter::matches (0 = no metadata or no match); NULL = no filter.
+int fvh_hybrid_search_with_filter(void* p, const float* q, uint32_t B, uint32_t d, uint64_t k,
+                                  int (*matches)(uint64_t, void*), void* user, double now, uint64_t* ids, float* dist,
+                                  uint32_t* counts) {
+  return ((HybridIndex*)p)->search_with_filter(q, B, d, k, matches, user, now, ids, dist, counts);
+}
 int fvh_hybrid_search_dev(void* p, const float* q_dev, uint32_t B, uint32_t d, uint64_t k, uint64_t ef, uint64_t nprobe,
                           int search_recent, int search_historical, uint64_t recent_k, uint64_t historical_k,
                           double now, uint64_t* ids, float* dist, uint32_t* counts) {

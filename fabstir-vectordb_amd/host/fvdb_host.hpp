@@ -6,7 +6,11 @@
 // bookkeeping, HNSW graph, heaps, visited sets, routing, timestamps); every distance comes
 // from the GPU through the C ABI.  Nothing in here computes a vector distance on the CPU.
 #pragma once
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
@@ -177,7 +181,7 @@ class HNSWIndex {
   // graph mirrored in HBM.  Same results; inserts always use the host walk.
   void set_device_traversal(bool on) { device_traversal_ = on; }
   bool device_traversal() const { return device_traversal_; }
-  uint64_t device_fallbacks() const { return n_fallback_; }
+  uint64_t device_fallbacks() const { return n_fallback_.load(); }
   // profiling on: summed HIP-event duration of the traversal kernel's launches since the last call
   int graph_kernel_times(float* ms_sum, uint32_t* launches, uint64_t* rows_scored, uint64_t* hops) {
     *ms_sum = 0.0f;
@@ -248,7 +252,10 @@ class HNSWIndex {
   DevSlot slots_[kSlots];
   void* d_q_ = nullptr;
   uint64_t d_q_cap_ = 0;
-  uint64_t n_fallback_ = 0;
+  std::atomic<uint64_t> n_fallback_{0};
+  // Searches may come from several host threads (HybridIndex leases a slot per call): the graph mirror is synced by
+  // one of them, the rare host-walk fallback and the standalone search()/search_dev() entry points are serialised.
+  std::mutex sync_mu_, walk_mu_, search_mu_;
 
   fvdb_ctx* ctx_;
   HNSWConfig cfg_;
@@ -322,7 +329,19 @@ class HybridIndex {
   int search_dev_begin(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
                        double now);
   int search_dev_end(uint32_t slot, uint64_t* ids, float* dist, uint32_t* counts);
+  // search_with_filter (src/hybrid/core.rs:513-549): ask for 3 k neighbours, keep the first k whose id the host
+  // application's metadata filter accepts.  `matches(id, user)` stands for `metadata_map.get(id)` +
+  // `MetadataFilter::matches` (an id without metadata does not match); NULL = no filter = plain search.
+  typedef int (*FilterFn)(uint64_t id, void* user);
+  int search_with_filter(const float* q, uint32_t B, uint32_t dim, uint64_t k, FilterFn matches, void* user, double now,
+                         uint64_t* ids, float* dist, uint32_t* counts);
+  // Concurrency (reference: tokio RwLock, searches = readers, src/hybrid/core.rs:457,466): search() / search_dev() /
+  // search_with_filter() may be called from any number of host threads; each call leases a free slot (stream,
+  // traversal state, IVF scratch set, result blocks) and returns it.  Mutations wait for those calls to finish.
+  // The explicit search_dev_begin/_end pair is for ONE thread keeping several batches in flight; while such a batch
+  // is uncollected, mutations are refused (INVALID) rather than waited for.
   bool busy() const {  // some batch is in flight: inserts / deletes are refused until it is collected
+    std::lock_guard<std::mutex> lk(slot_mu_);
     for (const Slot& s : slots_)
       if (s.active) return true;
     return false;
@@ -358,6 +377,16 @@ class HybridIndex {
   static double age_of(double now, double ts) { return now - ts < 0 ? 0.0 : now - ts; }
   int search_impl(const float* q, bool q_on_device, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
                   double now, uint64_t* ids, float* dist, uint32_t* counts);
+  int begin_impl(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg);
+  uint64_t migrate_locked(double threshold_s, double now);
+  bool busy_unlocked() const {
+    for (const Slot& s : slots_)
+      if (s.active) return true;
+    return false;
+  }
+  mutable std::shared_mutex rw_;   // searches of the blocking entry points: shared; mutations: unique
+  mutable std::mutex slot_mu_;     // Slot::active
+  std::condition_variable slot_cv_;
   fvdb_ctx* ctx_ivf_;
   struct Slot {  // one batch in flight
     void *d_hid = nullptr, *d_hd = nullptr, *d_hc = nullptr;  // device result buffers of the IVF part
@@ -366,6 +395,8 @@ class HybridIndex {
     fvdb_event* ivf_done = nullptr;
     fvdb_ctx* ivf_ctx = nullptr;  // slot 0 borrows ctx_ivf_, the others own a context (stream) each
     bool active = false, ivf_in_flight = false, hnsw_in_flight = false, recent = false;
+    void* d_q = nullptr;      // staging for host-resident query batches of the blocking entry points
+    uint64_t d_q_cap = 0;
     const float* q = nullptr;
     uint32_t B = 0, dim = 0, k = 0, rk = 0, hk = 0, ef = 0;
   };

@@ -515,6 +515,7 @@ void HNSWIndex::lane_advance(Lane& ln, const float* q, bool q_on_device, uint32_
 
 // mirror the adjacency lists into HBM (only when they changed)
 int HNSWIndex::sync_graph() {
+  std::lock_guard<std::mutex> lk(sync_mu_);  // the first of several concurrent searches after a mutation uploads
   if (!graph_) {
     int rc = fvdb_graph_create(store_, &graph_);
     if (rc) return rc;
@@ -539,7 +540,7 @@ int HNSWIndex::sync_graph() {
 bool HNSWIndex::device_path_ok(uint32_t ef) const {
   static const bool env_off = getenv("FVDB_HNSW_DEVICE") && atoi(getenv("FVDB_HNSW_DEVICE")) == 0;
   const uint32_t maxdeg = std::max(cfg_.max_connections, cfg_.max_connections_layer_0);
-  return device_traversal_ && !env_off && maxdeg + 1 <= 64 && ef <= 4096;
+  return device_traversal_ && !env_off && maxdeg <= 64 && ef <= 4096;  // one lane per neighbour
 }
 
 // whole batch in one launch, results copied to pinned host memory — all asynchronous on the slot's stream
@@ -609,6 +610,7 @@ int HNSWIndex::finish_failed(const float* q, bool q_on_device, uint32_t dim, uin
                              float* dist, uint32_t* counts, const std::vector<uint32_t>& failed) {
   if (failed.empty()) return FVDB_OK;
   n_fallback_ += failed.size();
+  std::lock_guard<std::mutex> lk(walk_mu_);  // the host walk's lanes and scorer are one set per index
   std::vector<float> hq((size_t)failed.size() * dim);
   for (size_t i = 0; i < failed.size(); ++i) {
     if (q_on_device) {
@@ -659,7 +661,13 @@ int HNSWIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint32_
   if (has_dim_ && dim != dim_) return FVDB_E_DIM;
   if (entry_lost_) return FVDB_E_NOT_FOUND;  // "Entry point node not found in index" (:422-429)
   if (B == 0 || k == 0) return FVDB_OK;
-  if (!device_path_ok(ef)) return search_host_walk(q, q_on_device, B, k, ef, ids, dist, counts);
+  // standalone entry point: slot 0 and one staging buffer => calls from several host threads take turns here
+  // (HybridIndex gives each of its concurrent searches a slot of its own through search_dev_begin/_end)
+  std::lock_guard<std::mutex> serial(search_mu_);
+  if (!device_path_ok(ef)) {
+    std::lock_guard<std::mutex> lk(walk_mu_);
+    return search_host_walk(q, q_on_device, B, k, ef, ids, dist, counts);
+  }
   const float* qd = q;
   if (!q_on_device) {  // stage the batch in HBM
     const uint64_t bytes = (uint64_t)B * dim * 4;

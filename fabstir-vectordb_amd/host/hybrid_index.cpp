@@ -1,6 +1,7 @@
 // hybrid_index.cpp — HybridIndex mirror (src/hybrid/core.rs): age routing, per-search
 // auto-migration, HNSW + IVF search and the stable merge.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +20,7 @@ HybridIndex::~HybridIndex() {
     if (sl.d_hid) fvdb_dev_free(ctx_ivf_, sl.d_hid);  // the other pointers are carved out of these two blocks
     if (sl.h_hid) fvdb_host_free(ctx_ivf_, sl.h_hid);
     if (sl.ivf_done) fvdb_event_destroy(sl.ivf_done);
+    if (sl.d_q) fvdb_dev_free(ctx_ivf_, sl.d_q);
     if (sl.ivf_ctx && sl.ivf_ctx != ctx_ivf_) fvdb_ctx_destroy(sl.ivf_ctx);
   }
   delete recent_;
@@ -52,6 +54,7 @@ int HybridIndex::set_ivf_centroids(const float* c, uint32_t dim) {
 int HybridIndex::insert_with_timestamp(uint64_t id, const float* v, uint32_t dim, double ts, double now,
                                        int64_t level) {
   if (!initialized_) return FVDB_E_NOT_INITIALIZED;
+  std::unique_lock<std::shared_mutex> w(rw_);  // waits for the blocking searches of other threads (write guard)
   if (busy()) return FVDB_E_INVALID;  // a search begun with search_dev_begin has not been collected yet
   if (timestamps_.count(id)) return FVDB_E_DUPLICATE;
   bool to_recent = !ivf_trained_ || age_of(now, ts) < cfg_.recent_threshold_s;
@@ -76,6 +79,7 @@ int HybridIndex::insert_with_timestamp(uint64_t id, const float* v, uint32_t dim
 int HybridIndex::bulk_insert(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const double* ts,
                              double now) {
   if (!initialized_) return FVDB_E_NOT_INITIALIZED;
+  std::unique_lock<std::shared_mutex> w(rw_);
   if (!ts_order_.empty() || busy()) return FVDB_E_INVALID;
   std::vector<uint64_t> rid, hid;
   std::vector<float> rv, hv;
@@ -130,6 +134,7 @@ static void plan_list_owners(const std::vector<uint64_t>& sizes, uint32_t world,
 int HybridIndex::bulk_insert_sharded(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const double* ts,
                                      double now, uint32_t rank, uint32_t world, uint32_t* owner_out) {
   if (!initialized_) return FVDB_E_NOT_INITIALIZED;
+  std::unique_lock<std::shared_mutex> w(rw_);
   if (!ts_order_.empty() || world == 0 || rank >= world || busy()) return FVDB_E_INVALID;
   std::vector<uint64_t> rid, hid;
   std::vector<float> rv, hv;
@@ -187,6 +192,7 @@ int HybridIndex::bulk_insert_sharded(const uint64_t* ids, const float* v, uint64
 // src/hybrid/core.rs:857-877
 int HybridIndex::from_parts(const uint64_t* ids, const double* ts, uint64_t n, uint64_t recent_count,
                             uint64_t historical_count, bool ivf_trained) {
+  std::unique_lock<std::shared_mutex> w(rw_);
   if (!ts_order_.empty() || busy()) return FVDB_E_INVALID;
   if (ivf_trained && !historical_->is_trained()) return FVDB_E_NOT_TRAINED;
   for (uint64_t i = 0; i < n; ++i) {
@@ -208,6 +214,7 @@ int HybridIndex::from_parts(const uint64_t* ids, const double* ts, uint64_t n, u
 
 // src/hybrid/core.rs:989-1012
 int HybridIndex::vacuum(uint64_t* hnsw_removed, uint64_t* ivf_removed) {
+  std::unique_lock<std::shared_mutex> w(rw_);
   if (busy()) return FVDB_E_INVALID;
   *hnsw_removed = recent_->vacuum();
   return historical_->vacuum(ivf_removed);
@@ -222,10 +229,17 @@ void HybridIndex::export_timestamps(uint64_t* ids, double* ts) const {
 
 // src/hybrid/core.rs:600-649 — copies into IVF, never removes from HNSW (:577-581)
 uint64_t HybridIndex::migrate_with_threshold(double threshold_s, double now) {
+  std::unique_lock<std::shared_mutex> w(rw_);
+  if (busy()) return 0;
+  return migrate_locked(threshold_s, now);
+}
+
+// the caller holds rw_ exclusively and no batch is in flight
+uint64_t HybridIndex::migrate_locked(double threshold_s, double now) {
   // The reference walks the whole timestamps map on every search (:606-617).  Same outcome, O(1) when
   // nothing is due: only ids still living in HNSW alone can migrate, and none is due while the oldest
   // of them is younger than the threshold.
-  if (!migration_due(threshold_s, now) || busy()) return 0;
+  if (!migration_due(threshold_s, now)) return 0;
   std::vector<Pending> keep;
   std::vector<uint64_t> due;
   double min_ts = 1e300;
@@ -299,15 +313,40 @@ static void merge_parts(uint32_t B, uint32_t k, uint32_t rk, uint32_t hk, bool h
   }
 }
 
+// Explicit pair for ONE thread that keeps several batches in flight (bench, pipelined servers).
 int HybridIndex::search_dev_begin(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
                                   double now) {
   if (slot >= kSlots) return FVDB_E_INVALID;
   Slot& sl = slots_[slot];
-  if (sl.active) return FVDB_E_INVALID;  // the previous batch of this slot was never collected
-  // a due migration moves rows between the two indexes (and may grow the list pool) under the batches still in
-  // flight: refuse, the caller collects them and begins again
-  if (initialized_ && cfg_.auto_migrate && busy() && migration_due(cfg_.recent_threshold_s, now)) return FVDB_E_INVALID;
-  sl = Slot{sl.d_hid, sl.d_hd, sl.d_hc, sl.h_hid, sl.h_hd, sl.h_hc, sl.cap, sl.ivf_done, sl.ivf_ctx};
+  bool others = false;
+  {
+    std::lock_guard<std::mutex> lk(slot_mu_);
+    if (sl.active) return FVDB_E_INVALID;  // the previous batch of this slot was never collected
+    others = busy_unlocked();
+  }
+  // per-search auto-migration (src/hybrid/core.rs:437-439), before this batch counts as in flight.  A due migration
+  // moves rows between the two indexes (and may grow the list pool) under the batches still in flight: refuse, the
+  // caller collects them and begins again
+  if (initialized_ && B != 0 && cfg.k != 0 && cfg_.auto_migrate) {
+    std::unique_lock<std::shared_mutex> w(rw_);
+    if (migration_due(cfg_.recent_threshold_s, now)) {
+      if (others || busy()) return FVDB_E_INVALID;
+      migrate_locked(cfg_.recent_threshold_s, now);
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lk(slot_mu_);
+    if (sl.active) return FVDB_E_INVALID;
+    sl.active = true;
+  }
+  const int rc = begin_impl(slot, q_dev, B, dim, cfg);
+  return rc;
+}
+
+// enqueue everything for the batch; the slot is already marked active by the caller
+int HybridIndex::begin_impl(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg) {
+  Slot& sl = slots_[slot];
+  sl.ivf_in_flight = sl.hnsw_in_flight = false;
   sl.q = q_dev;
   sl.B = B;
   sl.dim = dim;
@@ -316,9 +355,7 @@ int HybridIndex::search_dev_begin(uint32_t slot, const float* q_dev, uint32_t B,
   sl.hk = (uint32_t)(cfg.historical_k > 0 ? cfg.historical_k : cfg.k);
   sl.ef = (uint32_t)cfg.hnsw_ef;
   sl.recent = cfg.search_recent;
-  sl.active = true;
   if (!initialized_ || B == 0 || sl.k == 0) return FVDB_OK;
-  if (cfg_.auto_migrate) migrate_with_threshold(cfg_.recent_threshold_s, now);
   if (cfg.search_recent) {
     // the graph walk is latency-bound (one wave per query): enqueue it FIRST so that the list scan launched
     // next fills the rest of every SIMD and the two run concurrently
@@ -362,9 +399,23 @@ int HybridIndex::search_dev_begin(uint32_t slot, const float* q_dev, uint32_t B,
 }
 
 int HybridIndex::search_dev_end(uint32_t slot, uint64_t* ids, float* dist, uint32_t* counts) {
-  if (slot >= kSlots || !slots_[slot].active) return FVDB_E_INVALID;
+  if (slot >= kSlots) return FVDB_E_INVALID;
   Slot& sl = slots_[slot];
-  sl.active = false;
+  {
+    std::lock_guard<std::mutex> lk(slot_mu_);
+    if (!sl.active) return FVDB_E_INVALID;
+  }
+  struct Release {  // the slot is free again only when its buffers have been read
+    HybridIndex* h;
+    Slot* sl;
+    ~Release() {
+      {
+        std::lock_guard<std::mutex> lk(h->slot_mu_);
+        sl->active = false;
+      }
+      h->slot_cv_.notify_all();
+    }
+  } release{this, &sl};
   const uint32_t B = sl.B, k = sl.k;
   for (uint32_t b = 0; b < B; ++b) counts[b] = 0;
   for (size_t i = 0; i < (size_t)B * k; ++i) {
@@ -386,26 +437,22 @@ int HybridIndex::search_dev_end(uint32_t slot, uint64_t* ids, float* dist, uint3
   }
   if (sl.ivf_in_flight) {
     have_h = fvdb_event_wait(sl.ivf_ctx, sl.ivf_done) == FVDB_OK;
-    bool busy = false;
-    for (const Slot& o : slots_) busy = busy || o.active;
-    if (!busy) fvdb_ivf_profile_collect(historical_->device());  // stage timing only makes sense one batch at a time
+    bool others = false;
+    {
+      std::lock_guard<std::mutex> lk(slot_mu_);
+      for (const Slot& o : slots_) others = others || (o.active && &o != &sl);
+    }
+    if (!others) fvdb_ivf_profile_collect(historical_->device());  // stage timing only makes sense one batch at a time
   }
   merge_parts(B, k, sl.rk, sl.hk, have_r, rid.data(), rd.data(), rc_.data(), have_h, (const uint64_t*)sl.h_hid,
               (const float*)sl.h_hd, (const uint32_t*)sl.h_hc, ids, dist, counts);
   return FVDB_OK;
 }
 
+// The blocking entry points: any number of host threads.  A call holds the read side of rw_ from its migration
+// check to its merge and works in a slot leased for its duration.
 int HybridIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
                              double now, uint64_t* ids, float* dist, uint32_t* counts) {
-  if (q_on_device) {
-    int rc0 = search_dev_begin(0, q, B, dim, cfg, now);
-    if (rc0) {
-      slots_[0].active = false;
-      return rc0;
-    }
-    return search_dev_end(0, ids, dist, counts);
-  }
-  // host-resident queries: the two parts one after the other (each stages its own copy of the batch)
   const uint32_t k = (uint32_t)cfg.k;
   for (uint32_t b = 0; b < B; ++b) counts[b] = 0;
   for (size_t i = 0; i < (size_t)B * k; ++i) {
@@ -413,30 +460,125 @@ int HybridIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint3
     dist[i] = __builtin_huge_valf();
   }
   if (!initialized_ || B == 0 || k == 0) return FVDB_OK;
-  if (cfg_.auto_migrate) migrate_with_threshold(cfg_.recent_threshold_s, now);
-  const uint32_t rk = (uint32_t)(cfg.recent_k > 0 ? cfg.recent_k : cfg.k);
-  const uint32_t hk = (uint32_t)(cfg.historical_k > 0 ? cfg.historical_k : cfg.k);
-  std::vector<uint64_t> rid, hid;
-  std::vector<float> rd, hd;
-  std::vector<uint32_t> rc_(B, 0), hc(B, 0);
-  bool have_r = false, have_h = false;
-  if (cfg.search_historical && ivf_trained_) {
-    hid.resize((size_t)B * hk);
-    hd.resize((size_t)B * hk);
-    have_h = historical_->search(q, B, dim, hk, (uint32_t)cfg.ivf_n_probe, hid.data(), hd.data(), hc.data()) == FVDB_OK;
+  if (cfg_.auto_migrate) {  // src/hybrid/core.rs:437-439; the reference takes its write locks here too (:621-622)
+    bool due;
+    {
+      std::shared_lock<std::shared_mutex> r(rw_);
+      due = migration_due(cfg_.recent_threshold_s, now);
+    }
+    if (due) {
+      std::unique_lock<std::shared_mutex> w(rw_);
+      if (migration_due(cfg_.recent_threshold_s, now)) {
+        if (busy()) return FVDB_E_INVALID;  // batches begun with search_dev_begin are still uncollected
+        migrate_locked(cfg_.recent_threshold_s, now);
+      }
+    }
   }
-  if (cfg.search_recent) {
-    rid.resize((size_t)B * rk);
-    rd.resize((size_t)B * rk);
-    have_r = recent_->search(q, B, dim, rk, (uint32_t)cfg.hnsw_ef, rid.data(), rd.data(), rc_.data()) == FVDB_OK;
+  std::shared_lock<std::shared_mutex> r(rw_);
+  uint32_t slot = 0;
+  {
+    std::unique_lock<std::mutex> lk(slot_mu_);
+    slot_cv_.wait(lk, [&] {
+      for (const Slot& s : slots_)
+        if (!s.active) return true;
+      return false;
+    });
+    for (uint32_t i = kSlots; i-- > 0;)  // from the top: the low slots are the ones a pipelining caller names
+      if (!slots_[i].active) {
+        slot = i;
+        break;
+      }
+    slots_[slot].active = true;
   }
-  merge_parts(B, k, rk, hk, have_r, rid.data(), rd.data(), rc_.data(), have_h, hid.data(), hd.data(), hc.data(), ids, dist,
-              counts);
+  Slot& sl = slots_[slot];
+  auto give_back = [&]() {
+    {
+      std::lock_guard<std::mutex> lk(slot_mu_);
+      sl.active = false;
+    }
+    slot_cv_.notify_all();
+  };
+  const float* qd = q;
+  if (!q_on_device) {  // stage the batch in HBM once; both parts read it from there
+    const uint64_t bytes = (uint64_t)B * dim * 4;
+    if (bytes > sl.d_q_cap) {
+      if (sl.d_q) fvdb_dev_free(ctx_ivf_, sl.d_q);
+      sl.d_q = nullptr;
+      sl.d_q_cap = 0;
+      if (fvdb_dev_alloc(ctx_ivf_, bytes, &sl.d_q)) {
+        give_back();
+        return FVDB_E_OOM;
+      }
+      sl.d_q_cap = bytes;
+    }
+    if (!sl.ivf_ctx) {
+      if (slot == 0) sl.ivf_ctx = ctx_ivf_;
+      else if (fvdb_ctx_create(fvdb_ctx_device(ctx_ivf_), &sl.ivf_ctx)) {
+        give_back();
+        return FVDB_E_HIP;
+      }
+    }
+    for (uint64_t i = 0; i < (uint64_t)B * dim; ++i)
+      if (!(q[i] - q[i] == 0.0f)) {  // NaN / Inf: the reference panics in partial_cmp().unwrap()
+        give_back();
+        return FVDB_E_NONFINITE;
+      }
+    const int rcu = fvdb_dev_upload(sl.ivf_ctx, sl.d_q, q, bytes);  // waits on the slot's own stream only
+    if (rcu) {
+      give_back();
+      return rcu;
+    }
+    qd = (const float*)sl.d_q;
+  }
+  const int rc0 = begin_impl(slot, qd, B, dim, cfg);
+  if (rc0) {
+    if (sl.hnsw_in_flight || sl.ivf_in_flight) {  // drain what was enqueued before the failure
+      std::vector<uint64_t> ti((size_t)B * k);
+      std::vector<float> td((size_t)B * k);
+      std::vector<uint32_t> tc(B);
+      (void)search_dev_end(slot, ti.data(), td.data(), tc.data());
+    } else {
+      give_back();
+    }
+    return rc0;
+  }
+  return search_dev_end(slot, ids, dist, counts);
+}
+
+// src/hybrid/core.rs:513-549
+int HybridIndex::search_with_filter(const float* q, uint32_t B, uint32_t dim, uint64_t k, FilterFn matches, void* user,
+                                    double now, uint64_t* ids, float* dist, uint32_t* counts) {
+  HybridSearchConfig cfg;  // SearchConfig::default() with k (:419-423)
+  cfg.k = k;
+  if (!matches) return search_impl(q, false, B, dim, cfg, now, ids, dist, counts);
+  const uint64_t k3 = k * 3;  // k-oversampling, multiplier 3 (:527-529)
+  cfg.k = k3;
+  std::vector<uint64_t> ci((size_t)B * k3);
+  std::vector<float> cd((size_t)B * k3);
+  std::vector<uint32_t> cc(B, 0);
+  const int rc = search_impl(q, false, B, dim, cfg, now, ci.data(), cd.data(), cc.data());
+  if (rc) return rc;
+  for (uint32_t b = 0; b < B; ++b) {
+    uint32_t w = 0;
+    for (uint32_t i = 0; i < cc[b] && w < k; ++i) {  // candidates are sorted by distance already; truncate(k) (:543-546)
+      const uint64_t id = ci[(size_t)b * k3 + i];
+      if (!matches(id, user)) continue;
+      ids[(size_t)b * k + w] = id;
+      dist[(size_t)b * k + w] = cd[(size_t)b * k3 + i];
+      ++w;
+    }
+    counts[b] = w;
+    for (uint32_t i = w; i < k; ++i) {
+      ids[(size_t)b * k + i] = FVDB_NO_ID;
+      dist[(size_t)b * k + i] = __builtin_huge_valf();
+    }
+  }
   return FVDB_OK;
 }
 
 // delete: src/hybrid/core.rs:904-937
 int HybridIndex::remove(uint64_t id, double now) {
+  std::unique_lock<std::shared_mutex> w(rw_);
   if (busy()) return FVDB_E_INVALID;  // a search begun with search_dev_begin has not been collected yet
   auto it = timestamps_.find(id);
   if (it == timestamps_.end()) return FVDB_E_NOT_FOUND;

@@ -76,6 +76,7 @@ HOST_SIGNATURES = {
     "fvh_hybrid_bulk_insert": (i32, [vp, u64p, f32p, u64, u32, f64p, dbl]),
     "fvh_hybrid_bulk_insert_sharded": (i32, [vp, u64p, f32p, u64, u32, f64p, dbl, u32, u32, u32p]),
     "fvh_hybrid_search": (i32, [vp, f32p, u32, u32, u64, u64, u64, i32, i32, u64, u64, dbl, u64p, f32p, u32p]),
+    "fvh_hybrid_search_with_filter": (i32, [vp, f32p, u32, u32, u64, vp, vp, dbl, u64p, f32p, u32p]),
     "fvh_hybrid_search_dev": (i32, [vp, vp, u32, u32, u64, u64, u64, i32, i32, u64, u64, dbl, u64p, f32p, u32p]),
     "fvh_hybrid_search_dev_begin": (i32, [vp, u32, vp, u32, u32, u64, u64, u64, i32, i32, u64, u64, dbl]),
     "fvh_hybrid_search_dev_end": (i32, [vp, u32, u64p, f32p, u32p]),
@@ -253,6 +254,34 @@ class IVFIndex(_Base):
         return self._search(self.lib.fvh_ivf_search, queries, k, self.n_probe if n_probe is None else n_probe)
 
     search_with_config = search
+
+    _FILTER_FN = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_void_p)
+
+    def search_with_filter(self, queries, k, matches=None, now=0.0):
+        """HybridIndex::search_with_filter (src/hybrid/core.rs:513-549) in the host mirror: 3 k candidates with the
+        default search config, the first k whose id `matches(id)` accepts (None = no filter = plain search).  The
+        oversampling, the walk over the candidates and the truncation run below Python; `matches` stands for the
+        application's metadata_map lookup + MetadataFilter::matches."""
+        q = _rows(queries)
+        B = q.shape[0]
+        ids = np.empty((B, max(k, 1)), np.uint64)
+        ds = np.empty((B, max(k, 1)), np.float32)
+        cnt = np.zeros(B, np.uint32)
+        failure = []
+
+        def trampoline(rid, _user):
+            try:
+                return 1 if matches(int(rid)) else 0
+            except Exception as e:  # noqa: BLE001 — must not unwind through the C frames
+                failure.append(e)
+                return 0
+
+        cb = self._FILTER_FN(trampoline) if matches is not None else C.cast(None, self._FILTER_FN)
+        self._check(self.lib.fvh_hybrid_search_with_filter(self.h, _ptr(q, f32p), B, q.shape[1], k, C.cast(cb, C.c_void_p),
+                                                           None, float(now), _ptr(ids, u64p), _ptr(ds, f32p), _ptr(cnt, u32p)))
+        if failure:
+            raise failure[0]
+        return SearchResults(ids, ds, cnt)
     batch_search = search
 
     def mark_deleted(self, id):

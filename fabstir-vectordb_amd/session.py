@@ -197,18 +197,20 @@ class VectorDbSession:
                 flt = MetadataFilter.from_json(options["filter"])
             except FilterError as e:
                 raise SessionError(f"Invalid filter: {e}") from e
-        # with a filter: 3 k candidates, keep those whose metadata match, truncate (src/hybrid/core.rs:513-549)
-        kk = int(k) * 3 if flt is not None else int(k)
+        # with a filter: 3 k candidates, keep those whose metadata match, truncate — HybridIndex::search_with_filter of
+        # the host mirror (src/hybrid/core.rs:513-549); this side only answers "does this id's metadata match"
+        matches = None
+        if flt is not None:
+            def matches(rid):
+                key = self._rows.get(rid)
+                return key in self.metadata and flt.matches(self.metadata[key])
         try:
-            res = self.index.search(q.reshape(1, -1), kk, now=self.now)  # HybridIndex::search defaults (ef 50, nprobe 10)
+            res = self.index.search_with_filter(q.reshape(1, -1), int(k), matches, now=self.now)  # defaults: ef 50, nprobe 10
         except Exception as e:
             raise SessionError(f"Search failed: {e}") from e
         out = []
         ids, ds = res[0]
         pairs = list(zip(ids.tolist(), ds.tolist()))
-        if flt is not None:
-            pairs = [(rid, d) for rid, d in pairs
-                     if self._rows.get(rid) in self.metadata and flt.matches(self.metadata[self._rows[rid]])][:int(k)]
         for rid, d in pairs:
             score = np.float32(1.0) / (np.float32(1.0) + np.float32(d))
             if not score >= threshold:

@@ -20,9 +20,18 @@
  *    summed left to right, no FMA (src/core/vector_ops.rs:51-57).
  *  - ordering: ascending distance; exact ties keep scan order (probe rank, then position
  *    in the list) = what the reference's stable sort gives (src/ivf/core.rs:655,677).
- *  - threading: search entry points may be called concurrently on DIFFERENT contexts;
- *    calls on one context are serialised by the caller (reference: tokio RwLock,
- *    bindings/node/src/session.rs:253).  Mutations need external exclusion.
+ *  - threading (reference: searches hold a tokio RwLock READ guard, bindings/node/src/session.rs:253,
+ *    src/hybrid/core.rs:457,466 — many at once; inserts/deletes hold the write guard):
+ *      * the blocking host-pointer searches (fvdb_ivf_search, fvdb_ivf_search_all, fvdb_ivf_coarse) may be
+ *        called on ONE index from any number of host threads at once: each call leases a private scratch
+ *        set and stream inside the library and returns it when done;
+ *      * the `*_slot` entry points may be called concurrently for DIFFERENT slots (each slot = one scratch
+ *        set; the caller supplies the stream through `on`); two calls naming the same slot must use the same
+ *        stream and are then ordered by it;
+ *      * the stream-ordered `*_dev` entry points without a slot use set 0 on the index's own stream;
+ *      * a search never modifies the index object.  Mutations (set_centroids, train, add*, set_deleted,
+ *        clear, reserve, graph_upload, store_append) need external exclusion against searches and each other,
+ *        as the reference's write guard provides.
  */
 #ifndef FVDB_H
 #define FVDB_H
@@ -239,6 +248,37 @@ int fvdb_ivf_profile_collect(fvdb_ivf* ivf);  /* profiling mode 2: fold the last
  * keys/ids: G x B x k (device).  Exact because keys are unique. */
 int fvdb_merge_keys_dev(fvdb_ctx* ctx, const uint64_t* keys_dev, const uint64_t* ids_dev, uint32_t G, uint32_t B,
                         uint32_t k, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev);
+
+/* ---- top-k / merge utilities -----------------------------------------------------------
+ * The reference's public vector_ops helpers, batched: B independent rows per call, k <= FVDB_MAX_K.  Outputs are
+ * B x k (unused tail = FVDB_NO_ID / 0), out_counts[B] the number of entries.  A NaN score is FVDB_E_NONFINITE in
+ * the host-pointer forms (the reference panics in partial_cmp().unwrap()); the *_dev forms take device pointers,
+ * run on ctx's stream and do not inspect their input.
+ *  - fvdb_top_k_indices: top_k_indices (src/core/vector_ops.rs:12-22) — indices of the k largest scores, ties in
+ *    index order (stable sort).
+ *  - fvdb_top_k_indices_heap: top_k_indices_heap (:180-201) — BinaryHeap of size k with strict `>` replacement, then
+ *    a stable descending sort of the heap's vector: the tie behaviour of that heap is reproduced exactly.
+ *  - fvdb_streaming_top_k: StreamingTopK::add for every (id, score) of a row in order, then get_results()
+ *    (:204-263).  Heap order is the (reversed score, id) tuple order; u64 ids stand for VectorIds (a host that
+ *    needs the reference's tie order passes the first 8 bytes of the VectorId, big-endian).
+ *  - fvdb_merge_search_results: merge_search_results (:24-32) + SearchResult::deduplicate (src/core/types.rs:206-223)
+ *    — per row the concatenated result sets (id FVDB_NO_ID = padding); per id the smallest distance is kept (the
+ *    earliest entry on a tie), survivors ascending by distance, first k.  Where the reference's order among equal
+ *    distances comes out of HashMap iteration, first appearance of the id decides. */
+int fvdb_top_k_indices(fvdb_ctx* ctx, const float* scores /* B x n */, uint32_t B, uint64_t n, uint32_t k,
+                       uint64_t* out_idx, uint32_t* out_counts);
+int fvdb_top_k_indices_heap(fvdb_ctx* ctx, const float* scores, uint32_t B, uint64_t n, uint32_t k, uint64_t* out_idx,
+                            uint32_t* out_counts);
+int fvdb_top_k_indices_dev(fvdb_ctx* ctx, const float* scores_dev, uint32_t B, uint64_t n, uint32_t k, int heap,
+                           uint64_t* out_idx_dev, uint32_t* out_counts_dev);
+int fvdb_streaming_top_k(fvdb_ctx* ctx, const uint64_t* ids, const float* scores, uint32_t B, uint64_t n, uint32_t k,
+                         uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
+int fvdb_streaming_top_k_dev(fvdb_ctx* ctx, const uint64_t* ids_dev, const float* scores_dev, uint32_t B, uint64_t n,
+                             uint32_t k, uint64_t* out_ids_dev, float* out_scores_dev, uint32_t* out_counts_dev);
+int fvdb_merge_search_results(fvdb_ctx* ctx, const uint64_t* ids, const float* dist, uint32_t B, uint64_t n, uint32_t k,
+                              uint64_t* out_ids, float* out_dist, uint32_t* out_counts);
+int fvdb_merge_search_results_dev(fvdb_ctx* ctx, const uint64_t* ids_dev, const float* dist_dev, uint32_t B, uint64_t n,
+                                  uint32_t k, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_counts_dev);
 
 /* ---- candidate scoring (HNSW) --------------------------------------------------------
  * Replaces euclidean_distance at src/hnsw/core.rs:279,434,487,515 (search_layer) and

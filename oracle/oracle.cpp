@@ -806,6 +806,71 @@ void orc_top_k_indices_heap(const float* scores, uint64_t n, uint64_t k, uint64_
   *out_n = res.size();
 }
 
+// src/core/vector_ops.rs:204-263 — StreamingTopK: BinaryHeap<(OrderedFloat, VectorId)>, OrderedFloat's order reversed
+// (:219-230) so the root is the smallest score; tuples compare the id next, so among equal scores the LARGER id is
+// nearer the root and is evicted first.  add(): strict `>` against the root's score; get_results(): heap order
+// (into_iter), stable sort by score descending.  Ids are u64 here (numeric order stands for VectorId's byte order).
+void orc_streaming_top_k(const uint64_t* ids, const float* scores, uint64_t n, uint64_t k, uint64_t* out_ids,
+                         float* out_scores, uint64_t* out_n) {
+  *out_n = 0;
+  struct It {
+    float s;
+    uint64_t id;
+  };
+  auto le = [](const It& a, const It& b) { return a.s > b.s || (a.s == b.s && a.id <= b.id); };  // a <= b in tuple order
+  std::vector<It> h;
+  auto sift_up = [&](size_t start, size_t pos) {
+    It elt = h[pos];
+    while (pos > start) {
+      size_t parent = (pos - 1) / 2;
+      if (le(elt, h[parent])) break;
+      h[pos] = h[parent];
+      pos = parent;
+    }
+    h[pos] = elt;
+  };
+  auto pop = [&]() {
+    It item = h.back();
+    h.pop_back();
+    if (!h.empty()) {
+      std::swap(item, h[0]);
+      size_t end = h.size(), pos = 0;
+      It elt = h[0];
+      size_t child = 1;
+      const size_t lim = end >= 2 ? end - 2 : 0;
+      while (child <= lim) {
+        if (le(h[child], h[child + 1])) child += 1;
+        h[pos] = h[child];
+        pos = child;
+        child = 2 * pos + 1;
+      }
+      if (child == end - 1) {
+        h[pos] = h[child];
+        pos = child;
+      }
+      h[pos] = elt;
+      sift_up(0, pos);
+    }
+  };
+  for (uint64_t i = 0; i < n; ++i) {
+    if (h.size() < k) {
+      h.push_back({scores[i], ids[i]});
+      sift_up(0, h.size() - 1);
+    } else if (!h.empty() && scores[i] > h[0].s) {
+      pop();
+      h.push_back({scores[i], ids[i]});
+      sift_up(0, h.size() - 1);
+    }
+  }
+  std::vector<It> res = h;
+  std::stable_sort(res.begin(), res.end(), [](const It& a, const It& b) { return a.s > b.s; });
+  for (size_t i = 0; i < res.size(); ++i) {
+    out_ids[i] = res[i].id;
+    out_scores[i] = res[i].s;
+  }
+  *out_n = res.size();
+}
+
 // src/core/vector_ops.rs:24-32 + src/core/types.rs:206-223 — dedup keeping the smaller
 // distance, sort ascending, take k.  (HashMap::into_values order is random in the reference;
 // insertion order of first appearance is used here, then a stable sort.)

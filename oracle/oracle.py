@@ -17,7 +17,7 @@ __all__ = [
     "build", "lib", "OracleError", "NotTrained", "DuplicateVector", "DimensionMismatch",
     "InsufficientTrainingData", "VectorNotFound", "NotInitialized", "InvalidConfig",
     "euclidean_distance_scalar", "dot_product_scalar", "cosine_similarity_scalar", "l2_batch",
-    "top_k_indices", "top_k_indices_heap", "merge_search_results", "rng_levels",
+    "top_k_indices", "top_k_indices_heap", "streaming_top_k", "merge_search_results", "rng_levels",
     "IVFIndex", "HNSWIndex", "HybridIndex",
 ]
 
@@ -102,6 +102,7 @@ def lib():
         "orc_top_k_indices": (None, [_f32p, u64, u64, _u64p, _u64p]),
         "orc_top_k_indices_heap": (None, [_f32p, u64, u64, _u64p, _u64p]),
         "orc_merge_search_results": (None, [_u64p, _f32p, u64, u64, _u64p, _f32p, _u64p]),
+        "orc_streaming_top_k": (None, [_u64p, _f32p, u64, u64, _u64p, _f32p, _u64p]),
         "orc_rng_levels": (None, [u64, u64, _i64p]),
         "orc_ivf_new": (vp, [u64, u64, u64, u64]),
         "orc_ivf_free": (None, [vp]),
@@ -200,6 +201,17 @@ def top_k_indices(scores, k):
 
 def top_k_indices_heap(scores, k):
     return _topk(lib().orc_top_k_indices_heap, scores, k)
+
+
+def streaming_top_k(ids, scores, k):
+    """StreamingTopK::add for every (id, score) in order, then get_results(): [(id, score)] by descending score."""
+    ids = np.ascontiguousarray(ids, np.uint64)
+    sc = _f32(scores)
+    oi = np.empty(max(min(k, ids.size), 1), np.uint64)
+    od = np.empty(max(min(k, ids.size), 1), np.float32)
+    n = C.c_uint64(0)
+    lib().orc_streaming_top_k(_p(ids, _u64p), _p(sc, _f32p), ids.size, k, _p(oi, _u64p), _p(od, _f32p), C.byref(n))
+    return [(int(oi[i]), float(od[i])) for i in range(n.value)]
 
 
 def merge_search_results(result_sets, k):

@@ -159,6 +159,72 @@ def test_manifest_rules():
     assert e.value.kind == "ChunkOverlap"
 
 
+def test_malformed_manifest_structures_are_deserialization_errors():
+    # every malformed manifest.json must surface as PersistenceError (session.load_user_vectors maps only those):
+    # hand-picked damage of hnsw_structure / ivf_structure, then a structural fuzz of the golden manifest
+    from hypothesis import given, settings, strategies as hs
+    ok = {"version": 3, "chunk_size": 10000, "total_vectors": 5, "chunks": []}
+    good_h = {"entry_point": [7] * 32, "layers": [{"layer_id": 0, "node_count": 1}], "node_chunk_map": {"vec_00000000": "chunk-0"}}
+    good_i = {"centroids": [[0.0, 1.0], [2.0, 3.5]], "cluster_assignments": {"0": ["chunk-0"], "1": []}}
+    assert ck.manifest_from_json(json.dumps(dict(ok, hnsw_structure=good_h, ivf_structure=good_i)))["ivf_structure"] == good_i
+    bad_h = [[], "x", {}, dict(good_h, entry_point=[1, 2]), dict(good_h, entry_point="abc"), dict(good_h, entry_point=[300] * 32),
+             {k: v for k, v in good_h.items() if k != "node_chunk_map"}, dict(good_h, node_chunk_map=[1]),
+             {k: v for k, v in good_h.items() if k != "layers"}, dict(good_h, entry_point=[True] * 32)]
+    bad_i = [[], 3, {}, dict(good_i, centroids=[[0.0, 1.0], [2.0]]), dict(good_i, centroids=[["a", "b"]]), dict(good_i, centroids=7),
+             dict(good_i, cluster_assignments={"x": []}), dict(good_i, cluster_assignments={"-1": []}),
+             dict(good_i, cluster_assignments=[0]), {"centroids": []}]
+    for h in bad_h:
+        with pytest.raises(ck.PersistenceError) as e:
+            ck.manifest_from_json(json.dumps(dict(ok, hnsw_structure=h)))
+        assert e.value.kind == "Deserialization", h
+    for i in bad_i:
+        with pytest.raises(ck.PersistenceError) as e:
+            ck.manifest_from_json(json.dumps(dict(ok, ivf_structure=i)))
+        assert e.value.kind == "Deserialization", i
+    with pytest.raises(ck.PersistenceError):
+        ck.manifest_from_json(json.dumps(dict(ok, deleted_vectors={"a": 1})))
+
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chunked_small", "idx", "manifest.json")))
+    junk = hs.one_of(hs.none(), hs.booleans(), hs.integers(-5, 300), hs.text(max_size=4), hs.lists(hs.integers(0, 9), max_size=3),
+                     hs.dictionaries(hs.text(max_size=3), hs.integers(0, 3), max_size=2))
+
+    def paths(node, pre=()):
+        out = [pre]
+        if isinstance(node, dict):
+            for k, v in node.items():
+                if k != "chunks" and len(pre) < 3:
+                    out += paths(v, pre + (k,))
+        return out
+
+    all_paths = [p for p in paths(gold) if p]
+
+    @settings(max_examples=400, deadline=None)
+    @given(hs.sampled_from(all_paths), junk, hs.booleans())
+    def mutate(path, value, delete):
+        m = json.loads(json.dumps(gold))
+        node = m
+        for k in path[:-1]:
+            node = node[k]
+        if delete:
+            del node[path[-1]]
+        else:
+            node[path[-1]] = value
+        try:
+            got = ck.manifest_from_json(json.dumps(m))
+        except ck.PersistenceError as e:
+            assert e.kind in ("Deserialization", "IncompatibleVersion")
+            return
+        # accepted: the structures have the shapes load_index_chunked indexes without further checks
+        for s_ in (got["hnsw_structure"],):
+            assert s_ is None or (len(s_["entry_point"]) == 32 and isinstance(s_["node_chunk_map"], dict))
+        iv = got["ivf_structure"]
+        if iv is not None:
+            np.asarray(iv["centroids"], np.float32).reshape(len(iv["centroids"]), -1)
+            assert all(int(k) >= 0 for k in iv["cluster_assignments"])
+
+    mutate()
+
+
 def test_timestamps():
     assert ck.parse_timestamp("1970-01-01T00:00:00Z") == 0.0
     assert ck.parse_timestamp("2025-11-28T10:20:30.250Z") == ck.parse_timestamp("2025-11-28T10:20:30Z") + 0.25

@@ -371,6 +371,61 @@ def test_hybrid_parity_with_oracle(fv, ctx):
     assert any(len(set(rg.ids[b, : rg.counts[b]].tolist())) < rg.counts[b] for b in range(len(rg)))
 
 
+def test_hybrid_auto_migration_on_device_query_path(fv, ctx):
+    # the per-search auto-migration (src/hybrid/core.rs:437-439) must also run when the queries are resident in HBM
+    # (search_dev, search_dev_begin/_end): counts and the duplicate-bearing merged lists equal the oracle's
+    n, d, nlist = 700, 20, 6
+    x = mixture(n, d, n_comp=6, seed=57)
+    cents = x[:nlist].copy()
+    now = 1000 * DAY
+    ages = np.where(np.random.default_rng(3).random(n) < 0.3, 1 * DAY, 30 * DAY)
+    levels = orc.rng_levels(80, n)
+    kw = dict(max_connections=8, max_connections_layer_0=16, ef_construction=40, n_clusters=nlist, n_probe=3)
+    q = mixture(40, d, n_comp=6, seed=58)
+    for mode in ("search_dev", "begin_end"):
+        g, o = fv.HybridIndex(ctx, **kw), orc.HybridIndex(**kw)
+        g.set_ivf_centroids(cents)
+        o.set_ivf_centroids(cents)
+        for i in range(n):
+            g.insert_with_timestamp(i, x[i], now - ages[i], now, int(levels[i]))
+            o.insert_with_timestamp(i, x[i], now - ages[i], now, int(levels[i]))
+        qd = g.ctx.upload(q)
+        later = now + 10 * DAY
+        if mode == "search_dev":
+            rg = g.search_dev(qd, q.shape[0], 10, now=later, dim=d)
+        else:
+            g.search_dev_begin(2, qd, q.shape[0], 10, now=later, dim=d)
+            rg = g.search_dev_end(2)
+        oi, od, oc = o.batch_search(q, 10, now=later)
+        assert g.recent_count() == o.recent_count() == 0
+        assert g.historical_count() == o.historical_count() == n
+        assert_same_results(rg, oi, od, oc)
+        assert any(len(set(rg.ids[b, : rg.counts[b]].tolist())) < rg.counts[b] for b in range(len(rg)))
+
+
+def test_device_traversal_layer0_degree_64(fv, ctx):
+    # max_connections_layer_0 = 64: a full neighbour list occupies all 64 lanes of the traversal wavefront
+    n, d = 1500, 16
+    x = mixture(n, d, n_comp=4, sigma=1.0, seed=66)
+    ids = np.arange(n, dtype=np.uint64)
+    levels = orc.rng_levels(81, n)
+    gh, oh = fv.HNSWIndex(ctx, 32, 64, 100, seed=81), orc.HNSWIndex(32, 64, 100, seed=81)
+    gh.batch_insert(ids, x, levels)
+    oh.batch_insert(ids, x, levels)
+    same_graph(gh, oh, ids)
+    assert max(len(gh.neighbors(i, 0)) for i in range(n)) == 64
+    q = mixture(50, d, n_comp=4, sigma=1.0, seed=67)
+    assert gh.device_traversal()
+    for k, ef in ((10, 50), (20, 100)):
+        dev = gh.search(q, k, ef)
+        gh.set_device_traversal(False)
+        host = gh.search(q, k, ef)
+        gh.set_device_traversal(True)
+        assert np.array_equal(dev.ids, host.ids) and np.array_equal(bits(dev.distances), bits(host.distances))
+        assert_same_results(dev, *oh.batch_search(q, k, ef))
+    assert gh.device_fallbacks() == 0
+
+
 def test_hybrid_batches_in_flight_match_one_at_a_time(fv, ctx):
     # search_dev_begin / search_dev_end: several batches in flight (graph walks on their own streams, IVF chains
     # queued on one) give, slot by slot, exactly the results of the one-at-a-time search and of the oracle

@@ -98,6 +98,16 @@ def test_streaming_top_k_values():
     assert [scores[i] for i in idx] == [0.9, 0.8, 0.7]
 
 
+def test_streaming_top_k_struct():
+    # tests/core/vector_ops_advanced.rs:102-124 through StreamingTopK itself (vec_0..vec_4 -> ids 0..4): top 3 scores
+    # 0.9, 0.8, 0.7 in that order; k larger than the stream returns everything, sorted
+    got = orc.streaming_top_k([0, 1, 2, 3, 4], [0.5, 0.9, 0.3, 0.7, 0.8], 3)
+    assert [g[0] for g in got] == [1, 4, 3]
+    assert [g[1] for g in got] == pytest.approx([0.9, 0.8, 0.7])
+    assert [g[0] for g in orc.streaming_top_k([7, 8], [0.1, 0.2], 5)] == [8, 7]
+    assert orc.streaming_top_k([1, 2], [0.1, 0.2], 0) == []
+
+
 def test_result_merging_dedup_keeps_min():
     # tests/core/vector_ops.rs:37-71   ids: a=1, b=2, c=3
     merged = orc.merge_search_results([[(1, 0.1), (2, 0.3)], [(2, 0.2), (3, 0.4)]], 3)
