@@ -111,6 +111,19 @@ SIGNATURES = {
     "fvdb_streaming_top_k_dev": (i32, [vp, vp, vp, u32, u64, u32, vp, vp, vp]),
     "fvdb_merge_search_results": (i32, [vp, u64p, f32p, u32, u64, u32, u64p, f32p, u32p]),
     "fvdb_merge_search_results_dev": (i32, [vp, vp, vp, u32, u64, u32, vp, vp, vp]),
+    "fvdb_comm_unique_id": (i32, [vp]),
+    "fvdb_comm_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
+    "fvdb_comm_create_hosted": (i32, [vp, i32, i32, vp, vp, C.POINTER(vp)]),
+    "fvdb_comm_destroy": (None, [vp]),
+    "fvdb_comm_rank": (i32, [vp]),
+    "fvdb_comm_world": (i32, [vp]),
+    "fvdb_comm_all_gather_dev": (i32, [vp, vp, vp, vp, sz]),
+    "fvdb_comm_all_to_all_dev": (i32, [vp, vp, vp, vp, sz]),
+    "fvdb_sharded_create": (i32, [vp, vp, C.POINTER(vp)]),
+    "fvdb_sharded_destroy": (None, [vp]),
+    "fvdb_sharded_out_rows": (u32, [vp, u32, i32]),
+    "fvdb_ivf_search_sharded_begin": (i32, [vp, vp, u32, vp, u32, u32, u32, i32, vp, vp, vp]),
+    "fvdb_ivf_search_sharded_end": (i32, [vp, vp, u32]),
 }
 
 _lib = None

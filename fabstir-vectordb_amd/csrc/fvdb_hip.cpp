@@ -215,6 +215,7 @@ struct fvdb_ivf : IvfScratch {
   uint32_t lease_busy = 0;  // bit i: set i is out (under mu)
   std::mutex mu;            // list table upload, lease bookkeeping, AUTO-mode counters
   std::condition_variable lease_cv;
+  std::atomic<IvfScratch*> last_set{nullptr};  // scratch set of the most recent search (diagnostic entry points)
   fvdb_ctx* ctx = nullptr;
   uint32_t d = 0, dpad = 0, d4 = 0, nlist = 0;
   bool trained = false;
@@ -1391,6 +1392,7 @@ static int search_common(fvdb_ivf* ivf, const Env& E, const float* q_dev, uint32
     rc = finish_profile(ivf, E, !all, true);
     if (rc) return rc;
   }
+  ivf->last_set.store(E.S);
   return FVDB_OK;
 }
 
@@ -1590,11 +1592,20 @@ int fvdb_ivf_set_scan_mode(fvdb_ivf* ivf, int mode) {
   return FVDB_OK;
 }
 
+// the diagnostic entry points below describe the most recent search on the index, whichever scratch set it ran with
+// (call them with no search in flight)
+static IvfScratch& last_scratch(fvdb_ivf* ivf) {
+  IvfScratch* S = ivf->last_set.load();
+  return S ? *S : *ivf;
+}
+
 int fvdb_ivf_scan_survivors(fvdb_ivf* ivf, uint32_t* out, uint32_t B) {
   fvdb_ctx* ctx = ivf->ctx;
-  if (!ivf->s_scnt.p || ivf->s_scnt.cap < (size_t)B * 4) FAIL(ctx, FVDB_E_INVALID, "no matrix-core scan of that size has run");
+  IvfScratch& S = last_scratch(ivf);
+  if (!S.s_scnt.p || S.s_scnt.cap < (size_t)B * 4) FAIL(ctx, FVDB_E_INVALID, "no matrix-core scan of that size has run");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipMemcpyAsync(out, ivf->s_scnt.p, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  HIPCHK(ctx, hipMemcpyAsync(out, S.s_scnt.p, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FVDB_OK;
 }
@@ -1603,18 +1614,20 @@ int fvdb_ivf_scan_survivor_dump(fvdb_ivf* ivf, uint32_t query, uint32_t max_n, u
                                 uint32_t* n_out) {
   fvdb_ctx* ctx = ivf->ctx;
   *n_out = 0;
-  if (!ivf->s_scnt.p || !ivf->s_surv.p || ivf->s_scnt.cap < (size_t)(query + 1) * 4)
+  IvfScratch& S = last_scratch(ivf);
+  if (!S.s_scnt.p || !S.s_surv.p || S.s_scnt.cap < (size_t)(query + 1) * 4)
     FAIL(ctx, FVDB_E_INVALID, "no matrix-core scan holding that query has run");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipDeviceSynchronize());
   uint32_t cnt = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&cnt, ivf->s_scnt.as<uint32_t>() + query, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(&cnt, S.s_scnt.as<uint32_t>() + query, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   const uint32_t n = std::min(std::min(cnt, kMfmaCmax), max_n);
   std::vector<uint32_t> sv((size_t)n * 2);
   if (n) {
-    HIPCHK(ctx, hipMemcpyAsync(sv.data(), (const char*)ivf->s_surv.p + (size_t)query * kMfmaCmax * 8, (size_t)n * 8,
+    HIPCHK(ctx, hipMemcpyAsync(sv.data(), (const char*)S.s_surv.p + (size_t)query * kMfmaCmax * 8, (size_t)n * 8,
                                hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(v, ivf->s_sdist.as<float>() + (size_t)query * kMfmaCmax, (size_t)n * 4, hipMemcpyDeviceToHost,
+    HIPCHK(ctx, hipMemcpyAsync(v, S.s_sdist.as<float>() + (size_t)query * kMfmaCmax, (size_t)n * 4, hipMemcpyDeviceToHost,
                                ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
@@ -1652,12 +1665,14 @@ int fvdb_ivf_coarse_fallbacks(fvdb_ivf* ivf, uint64_t* out) {
 
 int fvdb_ivf_last_stats(fvdb_ivf* ivf, fvdb_search_stats* out) {
   fvdb_ctx* ctx = ivf->ctx;
-  if (!ivf->s_scalars.p) {
+  IvfScratch& S = last_scratch(ivf);
+  if (!S.s_scalars.p) {
     std::memset(out, 0, sizeof(*out));
     return FVDB_OK;
   }
   unsigned long long st[3];
-  HIPCHK(ctx, hipMemcpyAsync(st, ivf->s_scalars.as<uint32_t>() + 4, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  HIPCHK(ctx, hipMemcpyAsync(st, S.s_scalars.as<uint32_t>() + 4, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   out->rows_scanned = st[0];
   out->work_items = st[1];
@@ -2440,3 +2455,5 @@ int fvdb_graph_kernel_times(fvdb_graph* g, float* ms_sum, uint32_t* launches, ui
 }
 
 }  // extern "C"
+
+#include "comm_sharded.h"

@@ -205,6 +205,34 @@ int fvh_hybrid_search_dev_begin(void* p, uint32_t slot, const float* q_dev, uint
   c.historical_k = historical_k;
   return ((HybridIndex*)p)->search_dev_begin(slot, q_dev, B, d, c, now);
 }
+// multi-GPU: see HybridIndex::attach_comm / search_sharded_begin in fvdb_host.hpp
+int fvh_hybrid_attach_comm(void* p, fvdb_comm* comm) { return ((HybridIndex*)p)->attach_comm(comm); }
+int fvh_hybrid_search_sharded_begin(void* p, uint32_t slot, const float* q_dev, uint32_t B, uint32_t d, uint64_t k,
+                                    uint64_t ef, uint64_t nprobe, int search_recent, int search_historical,
+                                    uint64_t recent_k, uint64_t historical_k, int mode) {
+  HybridSearchConfig c;
+  c.k = k;
+  c.hnsw_ef = ef;
+  c.ivf_n_probe = nprobe;
+  c.search_recent = search_recent != 0;
+  c.search_historical = search_historical != 0;
+  c.recent_k = recent_k;
+  c.historical_k = historical_k;
+  return ((HybridIndex*)p)->search_sharded_begin(slot, q_dev, B, d, c, mode);
+}
+int fvh_hybrid_search_sharded_end(void* p, uint32_t slot, uint64_t* ids, float* dist, uint32_t* counts) {
+  return ((HybridIndex*)p)->search_sharded_end(slot, ids, dist, counts);
+}
+uint32_t fvh_hybrid_sharded_rows(void* p, uint32_t B, int mode) { return ((HybridIndex*)p)->sharded_rows(B, mode); }
+// pure host logic of the multi-GPU path, callable without a GPU (CPU tests): list placement and the hybrid merge
+void fvh_plan_list_owners(const uint64_t* sizes, uint32_t nlist, uint32_t world, uint32_t* owner) {
+  fvdbh::plan_list_owners_host(sizes, nlist, world, owner);
+}
+void fvh_merge_parts(uint32_t B, uint32_t k, uint32_t rk, uint32_t hk, const uint64_t* rid, const float* rd,
+                     const uint32_t* rc, const uint64_t* hid, const float* hd, const uint32_t* hc, uint64_t* ids,
+                     float* dist, uint32_t* counts) {
+  fvdbh::merge_parts_host(B, k, rk, hk, rid, rd, rc, hid, hd, hc, ids, dist, counts);
+}
 int fvh_hybrid_search_dev_end(void* p, uint32_t slot, uint64_t* ids, float* dist, uint32_t* counts) {
   return ((HybridIndex*)p)->search_dev_end(slot, ids, dist, counts);
 }

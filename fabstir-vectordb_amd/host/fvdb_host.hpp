@@ -329,6 +329,21 @@ class HybridIndex {
   int search_dev_begin(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
                        double now);
   int search_dev_end(uint32_t slot, uint64_t* ids, float* dist, uint32_t* counts);
+  // Multi-GPU (no counterpart in the reference): this rank's HybridIndex holds the inverted lists it owns
+  // (bulk_insert_sharded) and a replica of the graph.  attach_comm binds a communicator (fvdb_comm_create / _hosted);
+  // search_sharded_begin enqueues one step in `slot` — the IVF part through fvdb_ivf_search_sharded_begin (both
+  // exchanges and the merge by key on the slot's stream), the graph walk of this rank's own queries beside it — and
+  // search_sharded_end waits for the slot and applies the reference's hybrid merge.  mode FVDB_SHARD_WEAK: q_dev is
+  // this rank's own B queries, B result rows; FVDB_SHARD_STRONG: q_dev is the global batch (same on every rank),
+  // result rows = this rank's slice [r*per, min(B,(r+1)*per)) (sharded_rows()).  Per-search auto-migration is not run
+  // in this mode.  Every rank makes the same sequence of begin/end calls.
+  int attach_comm(fvdb_comm* comm);
+  int search_sharded_begin(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
+                           int mode);
+  int search_sharded_end(uint32_t slot, uint64_t* ids, float* dist, uint32_t* counts) {
+    return search_dev_end(slot, ids, dist, counts);
+  }
+  uint32_t sharded_rows(uint32_t B, int mode) const;  // rows search_sharded_end writes on this rank
   // search_with_filter (src/hybrid/core.rs:513-549): ask for 3 k neighbours, keep the first k whose id the host
   // application's metadata filter accepts.  `matches(id, user)` stands for `metadata_map.get(id)` +
   // `MetadataFilter::matches` (an id without metadata does not match); NULL = no filter = plain search.
@@ -377,7 +392,10 @@ class HybridIndex {
   static double age_of(double now, double ts) { return now - ts < 0 ? 0.0 : now - ts; }
   int search_impl(const float* q, bool q_on_device, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
                   double now, uint64_t* ids, float* dist, uint32_t* counts);
-  int begin_impl(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg);
+  int begin_impl(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
+                 int shard_mode = -1);
+  fvdb_comm* comm_ = nullptr;
+  fvdb_sharded* sharded_ = nullptr;
   uint64_t migrate_locked(double threshold_s, double now);
   bool busy_unlocked() const {
     for (const Slot& s : slots_)
@@ -415,5 +433,14 @@ class HybridIndex {
   double pending_min_ts_ = 1e300;           // oldest timestamp among them: O(1) "nothing is due" test
   uint64_t recent_count_ = 0, historical_count_ = 0;
 };
+
+// Pure host pieces of the multi-GPU path (also called by the CPU tests through the C wrappers):
+// greedy "largest list to the least loaded rank" placement, identical on every rank ...
+void plan_list_owners_host(const uint64_t* sizes, uint32_t nlist, uint32_t world, uint32_t* owner);
+// ... and HybridIndex::search_with_config's merge (src/hybrid/core.rs:476-485): recent results then historical ones,
+// stable sort by distance, truncate(k); B queries, rid/rd are B x rk, hid/hd B x hk (either part may be NULL)
+void merge_parts_host(uint32_t B, uint32_t k, uint32_t rk, uint32_t hk, const uint64_t* rid, const float* rd,
+                      const uint32_t* rc, const uint64_t* hid, const float* hd, const uint32_t* hc, uint64_t* ids,
+                      float* dist, uint32_t* counts);
 
 }  // namespace fvdbh

@@ -23,6 +23,7 @@ HybridIndex::~HybridIndex() {
     if (sl.d_q) fvdb_dev_free(ctx_ivf_, sl.d_q);
     if (sl.ivf_ctx && sl.ivf_ctx != ctx_ivf_) fvdb_ctx_destroy(sl.ivf_ctx);
   }
+  if (sharded_) fvdb_sharded_destroy(sharded_);
   delete recent_;
   delete historical_;
 }
@@ -189,6 +190,13 @@ int HybridIndex::bulk_insert_sharded(const uint64_t* ids, const float* v, uint64
   return FVDB_OK;
 }
 
+void plan_list_owners_host(const uint64_t* sizes, uint32_t nlist, uint32_t world, uint32_t* owner) {
+  std::vector<uint64_t> sz(sizes, sizes + nlist);
+  std::vector<uint32_t> ow;
+  plan_list_owners(sz, world ? world : 1, ow);
+  std::memcpy(owner, ow.data(), (size_t)nlist * sizeof(uint32_t));
+}
+
 // src/hybrid/core.rs:857-877
 int HybridIndex::from_parts(const uint64_t* ids, const double* ts, uint64_t n, uint64_t recent_count,
                             uint64_t historical_count, bool ivf_trained) {
@@ -313,6 +321,16 @@ static void merge_parts(uint32_t B, uint32_t k, uint32_t rk, uint32_t hk, bool h
   }
 }
 
+void merge_parts_host(uint32_t B, uint32_t k, uint32_t rk, uint32_t hk, const uint64_t* rid, const float* rd,
+                      const uint32_t* rc, const uint64_t* hid, const float* hd, const uint32_t* hc, uint64_t* ids,
+                      float* dist, uint32_t* counts) {
+  for (size_t i = 0; i < (size_t)B * k; ++i) {
+    ids[i] = FVDB_NO_ID;
+    dist[i] = __builtin_huge_valf();
+  }
+  merge_parts(B, k, rk, hk, rid != nullptr, rid, rd, rc, hid != nullptr, hid, hd, hc, ids, dist, counts);
+}
+
 // Explicit pair for ONE thread that keeps several batches in flight (bench, pipelined servers).
 int HybridIndex::search_dev_begin(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
                                   double now) {
@@ -343,11 +361,54 @@ int HybridIndex::search_dev_begin(uint32_t slot, const float* q_dev, uint32_t B,
   return rc;
 }
 
+int HybridIndex::attach_comm(fvdb_comm* comm) {
+  std::unique_lock<std::shared_mutex> w(rw_);
+  if (busy()) return FVDB_E_INVALID;
+  if (sharded_) fvdb_sharded_destroy(sharded_);
+  sharded_ = nullptr;
+  comm_ = comm;
+  if (!comm) return FVDB_OK;
+  if (!ivf_trained_ || !historical_->device()) return FVDB_E_NOT_TRAINED;
+  return fvdb_sharded_create(historical_->device(), comm, &sharded_);
+}
+
+uint32_t HybridIndex::sharded_rows(uint32_t B, int mode) const {
+  if (!comm_ || mode != FVDB_SHARD_STRONG) return B;
+  const uint32_t W = (uint32_t)fvdb_comm_world(comm_), r = (uint32_t)fvdb_comm_rank(comm_);
+  const uint32_t per = (B + W - 1) / W, lo = std::min(B, r * per), hi = std::min(B, (r + 1) * per);
+  return hi - lo;
+}
+
+int HybridIndex::search_sharded_begin(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim,
+                                      const HybridSearchConfig& cfg, int mode) {
+  if (slot >= kSlots || !sharded_ || (mode != FVDB_SHARD_WEAK && mode != FVDB_SHARD_STRONG)) return FVDB_E_INVALID;
+  {
+    std::lock_guard<std::mutex> lk(slot_mu_);
+    if (slots_[slot].active) return FVDB_E_INVALID;
+    slots_[slot].active = true;
+  }
+  return begin_impl(slot, q_dev, B, dim, cfg, mode);
+}
+
 // enqueue everything for the batch; the slot is already marked active by the caller
-int HybridIndex::begin_impl(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg) {
+int HybridIndex::begin_impl(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
+                            int shard_mode) {
   Slot& sl = slots_[slot];
   sl.ivf_in_flight = sl.hnsw_in_flight = false;
-  sl.q = q_dev;
+  // sharded: `q_own` / `Bown` are the queries whose final results this rank produces (the graph is replicated, so each
+  // rank walks it for those only); the IVF part is handed the batch as the mode defines it
+  const float* q_own = q_dev;
+  uint32_t Bown = B, ivf_rows = B;
+  if (shard_mode == FVDB_SHARD_STRONG) {
+    const uint32_t W = (uint32_t)fvdb_comm_world(comm_), r = (uint32_t)fvdb_comm_rank(comm_);
+    const uint32_t per = (B + W - 1) / W, lo = std::min(B, r * per), hi = std::min(B, (r + 1) * per);
+    q_own = q_dev + (size_t)lo * dim;
+    Bown = hi - lo;
+    ivf_rows = per;
+  }
+  const uint32_t B_ivf_in = B;
+  B = Bown;
+  sl.q = q_own;
   sl.B = B;
   sl.dim = dim;
   sl.k = (uint32_t)cfg.k;
@@ -355,17 +416,18 @@ int HybridIndex::begin_impl(uint32_t slot, const float* q_dev, uint32_t B, uint3
   sl.hk = (uint32_t)(cfg.historical_k > 0 ? cfg.historical_k : cfg.k);
   sl.ef = (uint32_t)cfg.hnsw_ef;
   sl.recent = cfg.search_recent;
-  if (!initialized_ || B == 0 || sl.k == 0) return FVDB_OK;
-  if (cfg.search_recent) {
+  if (!initialized_ || sl.k == 0 || (B == 0 && shard_mode < 0)) return FVDB_OK;
+  if (cfg.search_recent && B > 0) {
     // the graph walk is latency-bound (one wave per query): enqueue it FIRST so that the list scan launched
     // next fills the rest of every SIMD and the two run concurrently
     int rcb = 0;
-    sl.hnsw_in_flight = recent_->search_dev_begin(q_dev, B, dim, sl.rk, sl.ef, &rcb, slot);
+    sl.hnsw_in_flight = recent_->search_dev_begin(q_own, B, dim, sl.rk, sl.ef, &rcb, slot);
   }
   if (cfg.search_historical && ivf_trained_) {
-    // one device block and one pinned block per slot: [ids B*hk u64 | dist B*hk f32 | counts B u32] -> a single copy
-    const uint64_t need = (uint64_t)B * sl.hk;
-    const uint64_t bytes = need * 12 + (uint64_t)B * 4;
+    // one device block and one pinned block per slot: [ids R*hk u64 | dist R*hk f32 | counts R u32] -> a single copy
+    // (R = rows the IVF part writes: B, or the padded slice length in strong sharded mode)
+    const uint64_t need = (uint64_t)ivf_rows * sl.hk;
+    const uint64_t bytes = need * 12 + (uint64_t)ivf_rows * 4;
     if (bytes > sl.cap) {
       if (sl.d_hid) fvdb_dev_free(ctx_ivf_, sl.d_hid);
       if (sl.h_hid) fvdb_host_free(ctx_ivf_, sl.h_hid);
@@ -387,8 +449,18 @@ int HybridIndex::begin_impl(uint32_t slot, const float* q_dev, uint32_t B, uint3
     }
     fvdb_ctx* on = sl.ivf_ctx == ctx_ivf_ ? nullptr : sl.ivf_ctx;
     if (!sl.ivf_done && fvdb_event_create(sl.ivf_ctx, &sl.ivf_done)) return FVDB_E_HIP;
-    sl.ivf_in_flight = historical_->search_dev(q_dev, B, dim, sl.hk, (uint32_t)cfg.ivf_n_probe, (uint64_t*)sl.d_hid,
-                                               (float*)sl.d_hd, (uint32_t*)sl.d_hc, on, on ? slot : 0) == FVDB_OK;
+    if (shard_mode >= 0) {
+      // every rank must take part in the step's collectives even when its own slice is empty
+      if (dim != historical_->dimension()) return FVDB_E_DIM;
+      const int rcs = fvdb_ivf_search_sharded_begin(sharded_, on, on ? slot : 0, q_dev, B_ivf_in, sl.hk,
+                                                    (uint32_t)cfg.ivf_n_probe, shard_mode, (uint64_t*)sl.d_hid,
+                                                    (float*)sl.d_hd, (uint32_t*)sl.d_hc);
+      if (rcs) return rcs;
+      sl.ivf_in_flight = true;
+    } else {
+      sl.ivf_in_flight = historical_->search_dev(q_dev, B, dim, sl.hk, (uint32_t)cfg.ivf_n_probe, (uint64_t*)sl.d_hid,
+                                                 (float*)sl.d_hd, (uint32_t*)sl.d_hc, on, on ? slot : 0) == FVDB_OK;
+    }
     if (sl.ivf_in_flight) {
       // result copy rides the slot's stream right behind the chain, then the event
       if (fvdb_dev_download_async(sl.ivf_ctx, sl.h_hid, sl.d_hid, (size_t)bytes) || fvdb_event_record(sl.ivf_ctx, sl.ivf_done))

@@ -80,6 +80,12 @@ HOST_SIGNATURES = {
     "fvh_hybrid_search_dev": (i32, [vp, vp, u32, u32, u64, u64, u64, i32, i32, u64, u64, dbl, u64p, f32p, u32p]),
     "fvh_hybrid_search_dev_begin": (i32, [vp, u32, vp, u32, u32, u64, u64, u64, i32, i32, u64, u64, dbl]),
     "fvh_hybrid_search_dev_end": (i32, [vp, u32, u64p, f32p, u32p]),
+    "fvh_hybrid_attach_comm": (i32, [vp, vp]),
+    "fvh_hybrid_search_sharded_begin": (i32, [vp, u32, vp, u32, u32, u64, u64, u64, i32, i32, u64, u64, i32]),
+    "fvh_hybrid_search_sharded_end": (i32, [vp, u32, u64p, f32p, u32p]),
+    "fvh_hybrid_sharded_rows": (u32, [vp, u32, i32]),
+    "fvh_plan_list_owners": (None, [u64p, u32, u32, u32p]),
+    "fvh_merge_parts": (None, [u32, u32, u32, u32, u64p, f32p, u32p, u64p, f32p, u32p, u64p, f32p, u32p]),
     "fvh_hnsw_search_dev": (i32, [vp, vp, u32, u32, u32, u32, u64p, f32p, u32p]),
     "fvh_hnsw_search_dev_begin": (i32, [vp, u32, vp, u32, u32, u32, u32]),
     "fvh_hnsw_search_dev_end": (i32, [vp, u32, vp, u32, u32, u32, u32, u64p, f32p, u32p]),
@@ -255,33 +261,6 @@ class IVFIndex(_Base):
 
     search_with_config = search
 
-    _FILTER_FN = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_void_p)
-
-    def search_with_filter(self, queries, k, matches=None, now=0.0):
-        """HybridIndex::search_with_filter (src/hybrid/core.rs:513-549) in the host mirror: 3 k candidates with the
-        default search config, the first k whose id `matches(id)` accepts (None = no filter = plain search).  The
-        oversampling, the walk over the candidates and the truncation run below Python; `matches` stands for the
-        application's metadata_map lookup + MetadataFilter::matches."""
-        q = _rows(queries)
-        B = q.shape[0]
-        ids = np.empty((B, max(k, 1)), np.uint64)
-        ds = np.empty((B, max(k, 1)), np.float32)
-        cnt = np.zeros(B, np.uint32)
-        failure = []
-
-        def trampoline(rid, _user):
-            try:
-                return 1 if matches(int(rid)) else 0
-            except Exception as e:  # noqa: BLE001 — must not unwind through the C frames
-                failure.append(e)
-                return 0
-
-        cb = self._FILTER_FN(trampoline) if matches is not None else C.cast(None, self._FILTER_FN)
-        self._check(self.lib.fvh_hybrid_search_with_filter(self.h, _ptr(q, f32p), B, q.shape[1], k, C.cast(cb, C.c_void_p),
-                                                           None, float(now), _ptr(ids, u64p), _ptr(ds, f32p), _ptr(cnt, u32p)))
-        if failure:
-            raise failure[0]
-        return SearchResults(ids, ds, cnt)
     batch_search = search
 
     def mark_deleted(self, id):
@@ -540,6 +519,34 @@ class HybridIndex(_Base):
 
     search_with_config = search
 
+    _FILTER_FN = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_void_p)
+
+    def search_with_filter(self, queries, k, matches=None, now=0.0):
+        """HybridIndex::search_with_filter (src/hybrid/core.rs:513-549) in the host mirror: 3 k candidates with the
+        default search config, the first k whose id `matches(id)` accepts (None = no filter = plain search).  The
+        oversampling, the walk over the candidates and the truncation run below Python; `matches` stands for the
+        application's metadata_map lookup + MetadataFilter::matches."""
+        q = _rows(queries)
+        B = q.shape[0]
+        ids = np.empty((B, max(k, 1)), np.uint64)
+        ds = np.empty((B, max(k, 1)), np.float32)
+        cnt = np.zeros(B, np.uint32)
+        failure = []
+
+        def trampoline(rid, _user):
+            try:
+                return 1 if matches(int(rid)) else 0
+            except Exception as e:  # noqa: BLE001 — must not unwind through the C frames
+                failure.append(e)
+                return 0
+
+        cb = self._FILTER_FN(trampoline) if matches is not None else C.cast(None, self._FILTER_FN)
+        self._check(self.lib.fvh_hybrid_search_with_filter(self.h, _ptr(q, f32p), B, q.shape[1], k, C.cast(cb, C.c_void_p),
+                                                           None, float(now), _ptr(ids, u64p), _ptr(ds, f32p), _ptr(cnt, u32p)))
+        if failure:
+            raise failure[0]
+        return SearchResults(ids, ds, cnt)
+
     def search_dev(self, q_dev, B, k, now=0.0, hnsw_ef=50, ivf_n_probe=10, search_recent=True, search_historical=True,
                    recent_k=0, historical_k=0, dim=None):
         """Same search with the B x d query batch already resident in HBM (device pointer)."""
@@ -573,6 +580,29 @@ class HybridIndex(_Base):
         cnt = np.zeros(B, np.uint32)
         self._check(self.lib.fvh_hybrid_search_dev_end(self.h, slot, _ptr(ids, u64p), _ptr(ds, f32p), _ptr(cnt, u32p)))
         return SearchResults(ids, ds, cnt)
+
+    # ---- multi-GPU (sharded.py is the user-facing wrapper) ----
+    def attach_comm(self, comm_handle):
+        self._check(self.lib.fvh_hybrid_attach_comm(self.h, comm_handle))
+
+    def sharded_rows(self, B, mode):
+        return int(self.lib.fvh_hybrid_sharded_rows(self.h, B, mode))
+
+    def search_sharded_begin(self, slot, q_dev, B, k, mode, hnsw_ef=50, ivf_n_probe=10, search_recent=True,
+                             search_historical=True, recent_k=0, historical_k=0, dim=None):
+        self._check(self.lib.fvh_hybrid_search_sharded_begin(self.h, slot, q_dev, B, dim, k, hnsw_ef, ivf_n_probe,
+                                                             int(search_recent), int(search_historical), recent_k,
+                                                             historical_k, mode))
+        self._inflight = getattr(self, "_inflight", {})
+        self._inflight[slot] = (self.sharded_rows(B, mode), k)
+
+    def search_sharded_end(self, slot):
+        R, k = self._inflight.pop(slot)
+        ids = np.empty((max(R, 1), max(k, 1)), np.uint64)
+        ds = np.empty((max(R, 1), max(k, 1)), np.float32)
+        cnt = np.zeros(max(R, 1), np.uint32)
+        self._check(self.lib.fvh_hybrid_search_sharded_end(self.h, slot, _ptr(ids, u64p), _ptr(ds, f32p), _ptr(cnt, u32p)))
+        return SearchResults(ids[:R], ds[:R], cnt[:R])
 
     def delete(self, id, now=0.0):
         self._check(self.lib.fvh_hybrid_delete(self.h, int(id), float(now)))

@@ -56,7 +56,8 @@ typedef enum fvdb_status {
   FVDB_E_NONFINITE = 9,     /* NaN/Inf input (reference panics: partial_cmp().unwrap()) */
   FVDB_E_HIP = 10,          /* HIP runtime error (message via fvdb_last_error) */
   FVDB_E_OOM = 11,          /* device or host allocation failed */
-  FVDB_E_UNSUPPORTED = 12   /* k or nprobe above the compiled limit (FVDB_MAX_K) */
+  FVDB_E_UNSUPPORTED = 12,  /* k or nprobe above the compiled limit (FVDB_MAX_K) */
+  FVDB_E_RCCL = 13          /* RCCL missing or a collective failed (message via fvdb_last_error) */
 } fvdb_status;
 
 /* Largest k (and nprobe) served by the in-kernel wavefront top-k (64 lanes x 4 registers). */
@@ -337,6 +338,51 @@ int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const
  * <= 64 launches of the traversal kernel since the previous call, and how many were summed; and (always) the
  * rows scored and hops taken by all queries since the previous call (either may be NULL).  Synchronises. */
 int fvdb_graph_kernel_times(fvdb_graph* g, float* ms_sum, uint32_t* launches, uint64_t* rows_scored, uint64_t* hops);
+
+/* ---- multi-GPU: inverted lists sharded across the GPUs of a node, RCCL over xGMI -------------------------
+ * (BASELINE config C4; SURVEY §8e.  The reference has no distributed execution: what is preserved is the result —
+ * the merged answer equals the single-index answer bit for bit, because the selection keys are global.)
+ * One rank per GPU: a process (torch.distributed-style launch) or a host thread of one process, each with its own
+ * fvdb_ctx.  Lists are placed with fvdb_ivf_add_assigned (only the lists the rank owns) + fvdb_ivf_set_global_list_sizes;
+ * centroids are replicated.
+ *
+ * Communicator.  fvdb_comm_unique_id on rank 0 yields 128 bytes (ncclUniqueId) that the host ships to the other
+ * ranks out of band (its own rendezvous: TCP store, file, MPI ...); every rank then calls fvdb_comm_create
+ * (ncclCommInitRank).  librccl is loaded at that moment (dlopen), never by a single-GPU process.
+ * fvdb_comm_create_hosted is the same interface over a caller-supplied exchange of HOST buffers (tests, rehearsals on
+ * one GPU, fabrics RCCL does not drive): op 0 = all-gather (send: `bytes`, recv: world blocks of `bytes` in rank
+ * order), op 1 = all-to-all (send/recv: world blocks of `bytes`; block p of send goes to rank p); return 0 on success.
+ * Collectives of one communicator must be issued in the same order on every rank. */
+typedef struct fvdb_comm fvdb_comm;
+typedef int (*fvdb_exchange_fn)(void* user, int op, const void* send_host, void* recv_host, size_t bytes);
+int fvdb_comm_unique_id(void* out128);
+int fvdb_comm_create(fvdb_ctx* ctx, const void* id128, int world, int rank, fvdb_comm** out);
+int fvdb_comm_create_hosted(fvdb_ctx* ctx, int world, int rank, fvdb_exchange_fn fn, void* user, fvdb_comm** out);
+void fvdb_comm_destroy(fvdb_comm* comm);
+int fvdb_comm_rank(fvdb_comm* comm);
+int fvdb_comm_world(fvdb_comm* comm);
+/* Stream-ordered collectives on `on`'s stream (NULL = the communicator's context): recv_dev holds world blocks. */
+int fvdb_comm_all_gather_dev(fvdb_comm* comm, fvdb_ctx* on, const void* send_dev, void* recv_dev, size_t bytes);
+int fvdb_comm_all_to_all_dev(fvdb_comm* comm, fvdb_ctx* on, const void* send_dev, void* recv_dev, size_t bytes);
+
+/* Sharded search_with_config.  FVDB_SHARD_WEAK: q_dev = this rank's OWN B queries (global batch world*B); the rank
+ * gets the results of its own B queries.  FVDB_SHARD_STRONG: q_dev = the SAME B queries on every rank (global batch
+ * B); rank r gets the results of queries [r*per, min(B, (r+1)*per)), per = ceil(B/world) = fvdb_sharded_out_rows().
+ * begin enqueues the whole step — centroid ranking, exchange 1 (weak: all-gather of queries + probe lists), scan of
+ * the lists this rank owns, exchange 2 (all-to-all of the partial (key, id) lists), world-way merge by key — on
+ * `on`'s stream (NULL = the index's own) with the slot-th scratch set; no host synchronisation in between.  Outputs
+ * (device, fvdb_sharded_out_rows() x k) are valid after fvdb_ivf_search_sharded_end (or any wait on that stream).
+ * Every rank calls begin for the same slots in the same order. */
+#define FVDB_SHARD_WEAK 0
+#define FVDB_SHARD_STRONG 1
+typedef struct fvdb_sharded fvdb_sharded;
+int fvdb_sharded_create(fvdb_ivf* ivf, fvdb_comm* comm, fvdb_sharded** out);
+void fvdb_sharded_destroy(fvdb_sharded* s);
+uint32_t fvdb_sharded_out_rows(fvdb_sharded* s, uint32_t B, int mode);
+int fvdb_ivf_search_sharded_begin(fvdb_sharded* s, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t k,
+                                  uint32_t nprobe, int mode, uint64_t* out_ids_dev, float* out_dist_dev,
+                                  uint32_t* out_counts_dev);
+int fvdb_ivf_search_sharded_end(fvdb_sharded* s, fvdb_ctx* on, uint32_t slot);
 
 #ifdef __cplusplus
 }

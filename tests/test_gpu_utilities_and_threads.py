@@ -171,8 +171,10 @@ def test_concurrent_searches_with_a_writer(fv, ctx):
     for th in readers:
         th.join()
     assert not errors, errors[0]
-    r = g.search(extra[:8], 1, now=now, hnsw_ef=30, ivf_n_probe=12)
-    assert np.array_equal(r.ids[:, 0], np.arange(10_000, 10_008, dtype=np.uint64)) and np.all(r.distances[:, 0] < 1e-6)
+    # the rows that went to the inverted lists (even i: 30 days old) are found exactly when every list is probed
+    r = g.search(extra[0:16:2], 1, now=now, hnsw_ef=30, ivf_n_probe=12)
+    assert np.array_equal(r.ids[:, 0], np.arange(10_000, 10_016, 2, dtype=np.uint64)) and np.all(r.distances[:, 0] < 1e-6)
+    assert g.recent_count() + g.historical_count() == 1500 + extra.shape[0]
 
 
 def test_concurrent_ivf_searches_through_the_c_abi(fv, ctx):

@@ -1,6 +1,9 @@
-"""Multi-rank logic on CPU: shard planning, the hybrid merge, the all-gather packing, and a
-world_size-2 gloo run of the sharded IVF scheme (per-rank partial top-k with global keys,
-one all-gather, merge by key) checked against the single-index oracle."""
+"""Multi-rank logic that runs without a GPU: the host mirror's list placement and hybrid merge (product C++, called
+through libfvdb_host.so), and a world_size-2 gloo run of the sharded scheme in which the product's hosted-transport
+exchange function carries both exchange steps between two processes.  The per-rank partial top-k (a GPU kernel in the
+product) is supplied by the CPU oracle here; tests/test_00_gpu_sharded_ranks.py runs the same scheme end to end on
+the GPU through the C ABI."""
+import ctypes as C
 import os
 import socket
 
@@ -23,6 +26,9 @@ def test_plan_list_shards_balanced_and_deterministic():
         assert owner.max() < world and np.array_equal(owner, sh.plan_list_shards(sizes, world))
         loads = np.bincount(owner, weights=sizes, minlength=world)
         assert loads.max() - loads.min() <= sizes.max()  # LPT bound
+    # ties: equal lists are dealt round-robin in list order, lowest rank first
+    assert sh.plan_list_shards([5, 5, 5, 5], 2).tolist() == [0, 1, 0, 1]
+    assert sh.plan_list_shards([1, 9, 1], 3).tolist() == [1, 0, 2]
 
 
 def test_hybrid_merge_is_the_reference_merge():
@@ -42,27 +48,7 @@ def test_hybrid_merge_is_the_reference_merge():
         assert cnt[b] == len(allr)
         assert [t[1] for t in allr] == ids[b, :cnt[b]].tolist()
         assert [t[0] for t in allr] == ds[b, :cnt[b]].tolist()
-
-
-def test_pack_unpack_roundtrip():
-    rng = np.random.default_rng(2)
-    B, k, world = 10, 4, 3
-    slices, per = sh.query_slices(B, world)
-    bufs, truth = [], []
-    for r in range(world):
-        keys = rng.integers(0, 2**63, (B, k)).astype(np.uint64)
-        ids = rng.integers(0, 2**63, (B, k)).astype(np.uint64)
-        lo, hi = slices[r]
-        hi_, hd_ = rng.integers(0, 99, (hi - lo, k)).astype(np.uint64), rng.random((hi - lo, k)).astype(np.float32)
-        hc_ = rng.integers(0, k + 1, hi - lo).astype(np.uint32)
-        bufs.append(sh.pack_partials(keys, ids, hi_, hd_, hc_, per, k)[0])
-        truth.append((keys, ids, hi_, hd_, hc_))
-    keys, ids, h_ids, h_ds, h_cnt = sh.unpack_partials(np.concatenate(bufs), world, B, per, k)
-    for r in range(world):
-        lo, hi = slices[r]
-        assert np.array_equal(keys[r], truth[r][0]) and np.array_equal(ids[r], truth[r][1])
-        assert np.array_equal(h_ids[lo:hi], truth[r][2]) and np.array_equal(h_ds[lo:hi], truth[r][3])
-        assert np.array_equal(h_cnt[lo:hi], truth[r][4])
+        assert np.all(ids[b, cnt[b]:] == np.uint64(2**64 - 1)) and np.all(np.isinf(ds[b, cnt[b]:]))
 
 
 # ---- world_size 2 over gloo -----------------------------------------------------------------
@@ -74,15 +60,25 @@ def _free_port():
     return p
 
 
+def _exchange(fn, op, send, world):
+    """Call the product's fvdb_exchange_fn the way the C library does: raw host pointers."""
+    send = np.ascontiguousarray(send)
+    nbytes = send.nbytes if op == 0 else send.nbytes // world
+    recv = np.empty(world * nbytes, np.uint8)
+    rc = fn(None, op, send.ctypes.data_as(C.c_void_p), recv.ctypes.data_as(C.c_void_p), nbytes)
+    assert rc == 0
+    return recv
+
+
 def _rank_main(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    fn = sh.hosted_exchange(dist, torch, world, rank)  # what Comm.hosted hands to fvdb_comm_create_hosted
     n, d, nlist, B, k, nprobe = 3000, 16, 24, 21, 5, 6
     x = mixture(n, d, n_comp=10, seed=70)
-    q = mixture(B, d, n_comp=10, seed=71)
     cents = x[:nlist].copy()
     full = orc.IVFIndex(n_clusters=nlist, n_probe=nprobe)
     full.set_trained(cents)
@@ -90,42 +86,46 @@ def _rank_main(rank, world, port, out_dir):
     full.batch_insert(ids, x)
     clusters = full.assign(x)
     sizes = np.bincount(clusters, minlength=nlist)
-    owner = sh.plan_list_shards(sizes, world)
-    # this rank's partial result: rows of probed lists it owns, key = (distance bits << 32 | global seq)
-    keys = np.full((B, k), 2**64 - 1, np.uint64)
-    pids = np.full((B, k), 2**64 - 1, np.uint64)
-    for b in range(B):
-        cd = orc.l2_batch(q[b], cents)
+    owner = sh.plan_list_shards(sizes, world)  # product placement
+    # WEAK mode: every rank has its own queries; exchange 1 = all-gather of the query batches
+    q_own = mixture(B, d, n_comp=10, seed=71 + rank)
+    q_all = _exchange(fn, 0, q_own, world).view(np.float32).reshape(world * B, d)
+    ok = all(np.array_equal(q_all[r * B:(r + 1) * B], mixture(B, d, n_comp=10, seed=71 + r)) for r in range(world))
+    # this rank's partial result for ALL world*B queries: rows of probed lists it owns, key = (distance bits << 32 |
+    # global seq) — the oracle stands in for the GPU scan
+    keys = np.full((world * B, k), 2**64 - 1, np.uint64)
+    pids = np.full((world * B, k), 2**64 - 1, np.uint64)
+    for b in range(world * B):
+        cd = orc.l2_batch(q_all[b], cents)
         probes = np.argsort(cd, kind="stable")[:nprobe]
         cand = []
         base = 0
         for L in probes:
             members = np.nonzero(clusters == L)[0]  # insertion order = position in list
             if owner[L] == rank and members.size:
-                dist_ = orc.l2_batch(q[b], x[members])
+                dist_ = orc.l2_batch(q_all[b], x[members])
                 for pos, (m, dv) in enumerate(zip(members, dist_)):
                     cand.append(((int(np.float32(dv).view(np.uint32)) << 32) | (base + pos), int(ids[m])))
             base += -(-int(sizes[L]) // 64) * 64  # seq advances by the padded logical list length
         cand.sort()
         for i, (key, id_) in enumerate(cand[:k]):
             keys[b, i], pids[b, i] = key, id_
-    slices, per = sh.query_slices(B, world)
-    lo, hi = slices[rank]
-    empty = (np.empty((hi - lo, k), np.uint64), np.empty((hi - lo, k), np.float32), np.zeros(hi - lo, np.uint32))
-    buf, _ = sh.pack_partials(keys, pids, *empty, per, k)
-    mine = torch.from_numpy(buf.copy())
-    allb = torch.empty(world * mine.numel(), dtype=torch.int64)
-    dist.all_gather_into_tensor(allb, mine)
-    gk, gi, _, _, _ = sh.unpack_partials(allb.numpy(), world, B, per, k)
-    # merge by key (what fvdb_merge_keys_dev does on the GPU)
-    ok = True
+    # exchange 2 = all-to-all: block p (the partials of rank p's queries) goes to rank p
+    gk = _exchange(fn, 1, keys, world).view(np.uint64).reshape(world, B, k)
+    gi = _exchange(fn, 1, pids, world).view(np.uint64).reshape(world, B, k)
+    # merge by key (fvdb_merge_keys_dev on the GPU), then the reference's hybrid merge through the host mirror with an
+    # empty HNSW part
     for b in range(B):
         allc = sorted((int(gk[r, b, i]), int(gi[r, b, i])) for r in range(world) for i in range(k)
                       if gk[r, b, i] != np.uint64(2**64 - 1))[:k]
-        want = full.search(q[b], k, nprobe)
-        got_ids = [c[1] for c in allc]
-        got_ds = [np.uint32(c[0] >> 32).view(np.float32) for c in allc]
-        ok &= got_ids == want.ids.tolist() and got_ds == want.distances.tolist()
+        want = full.search(q_own[b], k, nprobe)
+        got_ids = np.asarray([c[1] for c in allc], np.uint64)
+        got_ds = np.asarray([np.uint32(c[0] >> 32).view(np.float32) for c in allc], np.float32)
+        m_ids, m_ds, m_cnt = sh.hybrid_merge(np.zeros((1, k), np.uint64), np.zeros((1, k), np.float32), np.zeros(1, np.uint32),
+                                             np.pad(got_ids, (0, k - got_ids.size))[None], np.pad(got_ds, (0, k - got_ds.size))[None],
+                                             np.asarray([got_ids.size], np.uint32), k)
+        ok &= m_cnt[0] == len(want) and m_ids[0, :m_cnt[0]].tolist() == want.ids.tolist()
+        ok &= m_ds[0, :m_cnt[0]].tolist() == want.distances.tolist()
     open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
     dist.barrier()
     dist.destroy_process_group()
