@@ -12,12 +12,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "common.h"
 #include "kernels_graph.h"
+#include "kernels_graph_fast.h"
 #include "kernels_misc.h"
 #include "kernels_scan.h"
 #include "kernels_coarse.h"
@@ -2391,16 +2393,72 @@ int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const
   gv.counters = (unsigned long long*)g->d_counters.p;
 #ifdef FVDB_GRAPH_STAMPS
   static unsigned long long* d_stamps = nullptr;
+  constexpr size_t kStampWords = 8 + 3 * 16384 + 4;  // 8 sums, then per query (cycles, hops, start tick) of the last launch
   if (!d_stamps) {
-    (void)hipMalloc(&d_stamps, 64);
-    (void)hipMemset(d_stamps, 0, 64);
+    (void)hipMalloc(&d_stamps, kStampWords * 8);
+    (void)hipMemset(d_stamps, 0, kStampWords * 8);
   }
   gv.stamps = d_stamps;
   {
-    unsigned long long h[8];
-    (void)hipMemcpy(h, d_stamps, 64, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[graph stamps, cumulative] pop %llu nbr %llu score %llu admit %llu | pending %llu scored-hops %llu hops %llu total %llu\n",
-            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(kStampWords);
+    (void)hipMemcpy(h.data(), d_stamps, kStampWords * 8, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[graph stamps, cumulative] s0 %llu s1 %llu s2 %llu s3 %llu | rows %llu rounds %llu hops %llu total %llu | score: issue %llu "
+            "first-block wait+products %llu other-block products %llu adds %llu\n",
+            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8 + 3 * 16384], h[8 + 3 * 16384 + 1], h[8 + 3 * 16384 + 2], h[8 + 3 * 16384 + 3]);
+    std::vector<unsigned long long> cyc, hp, rt;
+    {
+      // placement: HW_ID bits [3:0] wave, [5:4] simd, [11:8] cu, [12] sh, [15:13] se; top nibble = XCC
+      std::map<unsigned, unsigned> per_cu, per_simd;
+      unsigned late = 0;
+      unsigned long long first = ~0ull;
+      for (uint32_t q = 0; q < 16384; ++q)
+        if (h[8 + 3 * q]) first = std::min(first, h[8 + 3 * q + 1]);
+      for (uint32_t q = 0; q < 16384; ++q)
+        if (h[8 + 3 * q]) {
+          const unsigned hw = (unsigned)((h[8 + 3 * q] >> 32) & 0x0FFFFFFFu), xcc = (unsigned)(h[8 + 3 * q] >> 60);
+          const unsigned cu = (xcc << 16) | (hw & 0xFF00u);
+          per_cu[cu]++;
+          per_simd[(cu << 2) | ((hw >> 4) & 3)]++;
+          if (h[8 + 3 * q + 1] - first > 10000) late++;
+          h[8 + 3 * q] &= 0xFFFFFFFFull;
+        }
+      unsigned mx_cu = 0, mx_simd = 0;
+      for (auto& kv : per_cu) mx_cu = std::max(mx_cu, kv.second);
+      for (auto& kv : per_simd) mx_simd = std::max(mx_simd, kv.second);
+      fprintf(stderr, "[graph stamps, placement] CUs used %zu (max waves on one CU %u), SIMDs used %zu (max on one %u), waves starting > 100 us late: %u\n",
+              per_cu.size(), mx_cu, per_simd.size(), mx_simd, late);
+    }
+    for (uint32_t q = 0; q < 16384; ++q)
+      if (h[8 + 3 * q]) {
+        cyc.push_back(h[8 + 3 * q]);
+        hp.push_back(h[8 + 3 * q + 1]);
+        rt.push_back(h[8 + 3 * q + 2]);
+      }
+    if (!cyc.empty()) {
+      double csum = 0, rsum = 0;
+      for (size_t i = 0; i < cyc.size(); ++i) {
+        csum += (double)cyc[i];
+        rsum += (double)rt[i];
+      }
+      // hp = start tick (100 MHz), rt = lifetime ticks
+      unsigned long long t0 = ~0ull, t1 = 0;
+      for (size_t i = 0; i < cyc.size(); ++i) {
+        t0 = std::min(t0, hp[i]);
+        t1 = std::max(t1, hp[i] + rt[i]);
+      }
+      std::vector<unsigned long long> st;
+      for (size_t i = 0; i < cyc.size(); ++i) st.push_back(hp[i] - t0);
+      std::sort(cyc.begin(), cyc.end());
+      std::sort(st.begin(), st.end());
+      std::sort(rt.begin(), rt.end());
+      const size_t n = cyc.size();
+      fprintf(stderr, "[graph stamps, last launch] queries %zu  cycles p50 %llu max %llu | wave lifetime us p50 %.1f p99 %.1f max %.1f | clock %.2f GHz | "
+              "first start .. last end %.1f us; starts us: p25 %.1f p50 %.1f p75 %.1f p90 %.1f max %.1f\n", n, cyc[n / 2], cyc[n - 1],
+              rt[n / 2] / 100.0, rt[n * 99 / 100] / 100.0, rt[n - 1] / 100.0, csum / rsum / 10.0, (t1 - t0) / 100.0, st[n / 4] / 100.0,
+              st[n / 2] / 100.0, st[n * 3 / 4] / 100.0, st[n * 9 / 10] / 100.0, st[n - 1] / 100.0);
+    }
+    (void)hipMemset(d_stamps, 0, kStampWords * 8);
   }
 #endif
   hipEvent_t* ev = nullptr;
@@ -2412,14 +2470,50 @@ int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const
     }
     (void)hipEventRecord(ev[0], ctx->stream);
   }
-  if (rh)
+  // ef <= 63: the sorted-register kernel; a query in which two heap members meet with equal distances is re-run by
+  // the same wave with the reference's heaps restated (exact on ties)
+  static const bool no_fast = getenv("FVDB_GRAPH_NO_FAST") != nullptr;  // tuning aid / A-B
+  static const int fast_r = getenv("FVDB_GRAPH_FAST_R") ? atoi(getenv("FVDB_GRAPH_FAST_R")) : 0;
+  const uint32_t nb128 = (s->dpad + 127) / 128;
+  const bool fast = !no_fast && rh && nb128 <= 8 && g->n < 0x80000000u;
+  if (fast) {
+    int R = nb128 <= 3 ? 16 : (nb128 == 4 ? 12 : (nb128 <= 6 ? 8 : 6));  // rows per scoring round: registers R*NB*2
+    if (nb128 == 3 && (fast_r == 8 || fast_r == 12)) R = fast_r;
+    const uint32_t wave_lds = (uint32_t)((std::max(graph_fast_lds_bytes((uint32_t)R), lds) + 15) & ~(size_t)15);
+#define FVDB_FAST_LAUNCH(NB_, R_)                                                                                         \
+  do {                                                                                                                    \
+    if (4 * wave_lds > 48 * 1024)                                                                                         \
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)hnsw_search_fast_kernel<NB_, R_>,                                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * wave_lds)));                  \
+    hipLaunchKernelGGL((hnsw_search_fast_kernel<NB_, R_>), dim3(cdiv(B, 4)), dim3(256), 4 * wave_lds, ctx->stream, gv, qd, \
+                       B, k, ef, cand_cap, wave_lds, g->s_visited[slot].as<uint32_t>(), words,                            \
+                       g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev, out_counts_dev,              \
+                       out_status_dev);                                                                                   \
+  } while (0)
+    if (4 * (size_t)wave_lds > 160 * 1024) FAIL(ctx, FVDB_E_UNSUPPORTED, "dimension / ef too large for the on-chip traversal state");
+    switch (nb128) {
+      case 1: FVDB_FAST_LAUNCH(1, 16); break;
+      case 2: FVDB_FAST_LAUNCH(2, 16); break;
+      case 3:
+        if (R == 8) FVDB_FAST_LAUNCH(3, 8);
+        else if (R == 12) FVDB_FAST_LAUNCH(3, 12);
+        else FVDB_FAST_LAUNCH(3, 16);
+        break;
+      case 4: FVDB_FAST_LAUNCH(4, 12); break;
+      case 5:
+      case 6: FVDB_FAST_LAUNCH(6, 8); break;
+      default: FVDB_FAST_LAUNCH(8, 6); break;
+    }
+#undef FVDB_FAST_LAUNCH
+  } else if (rh) {
     hipLaunchKernelGGL(hnsw_search_kernel<true>, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
                        g->s_visited[slot].as<uint32_t>(), words, g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
                        out_counts_dev, out_status_dev);
-  else
+  } else {
     hipLaunchKernelGGL(hnsw_search_kernel<false>, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
                        g->s_visited[slot].as<uint32_t>(), words, g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
                        out_counts_dev, out_status_dev);
+  }
   if (ev) {
     (void)hipEventRecord(ev[1], ctx->stream);
     g->kev_n += 1;

@@ -4,12 +4,16 @@
 //
 // It executes HNSWIndex::search (src/hnsw/core.rs:398-467) and search_layer (:469-554) operation
 // for operation: the two heaps are std::collections::BinaryHeap restated (sift_up /
-// sift_down_to_bottom, driven by lane 0 so the order of heap operations — and therefore the
-// outcome of exact distance ties — is the reference's); a popped node's neighbours are filtered
+// sift_down_to_bottom; `nearest` in registers with wave-parallel pushes and pops for ef <= 63, `candidates` in LDS
+// with all lanes reading the ancestor chain at once — exactly the element moves of the serial routines, so the
+// outcome of exact distance ties is the reference's); a popped node's neighbours are filtered
 // through the visited set in list order; their distances are the reference's sequential f32 fold
-// (one lane per neighbour, rows staged through LDS with coalesced loads); the admission rule
-// (:517-531) is applied in neighbour order.  Results equal the host-side walk's bit for bit
+// (one lane per neighbour, each lane streaming its own row from L2 after a whole-hop line prefetch); the admission
+// rule (:517-531) is applied in neighbour order.  Results equal the host-side walk's bit for bit
 // (tests/test_gpu_host_mirror.py::test_device_traversal_*).
+//
+// Since round 2 this kernel is the EXACT-TIE path: batch searches run hnsw_search_fast_kernel (kernels_graph_fast.h)
+// first, and only queries in which two heap members met with equal distances (or ef > 64, or d > 1024) come here.
 #pragma once
 #include "common.h"
 #include "kernels_scan.h"
@@ -327,19 +331,16 @@ __host__ __device__ inline size_t graph_lds_bytes(uint32_t dpad, uint32_t ef, ui
   return (b + 15) & ~(size_t)15;
 }
 
+// The whole search of query `b` by the calling wavefront, with the reference's heaps restated (exact on distance ties).
+// `lds`: graph_lds_bytes(dpad, ef, cand_cap) bytes private to the wave.
 // RH: `nearest` in registers + wave-parallel heap pushes (ef <= 63); otherwise both heaps in LDS, driven by lane 0.
 template <bool RH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 3))) void hnsw_search_kernel(const GraphView g, const float* __restrict__ queries,
-                                                         uint32_t B, uint32_t k, uint32_t ef_final, uint32_t cand_cap,
-                                                         uint32_t* __restrict__ visited /* [B][words] zero on entry */,
-                                                         uint32_t words, uint32_t* __restrict__ touched /* [B][tcap] */,
-                                                         uint32_t tcap, uint32_t* __restrict__ out_nodes,
-                                                         float* __restrict__ out_dist, uint32_t* __restrict__ out_counts,
-                                                         uint32_t* __restrict__ out_status) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int lane = threadIdx.x;
-  const uint32_t b = blockIdx.x;
-  if (b >= B) return;
+__device__ __forceinline__ void hnsw_search_exact_body(const GraphView& g, const float* __restrict__ queries, uint32_t b, uint32_t k,
+                                                       uint32_t ef_final, uint32_t cand_cap, uint32_t* __restrict__ visited,
+                                                       uint32_t words, uint32_t* __restrict__ touched, uint32_t tcap,
+                                                       uint32_t* __restrict__ out_nodes, float* __restrict__ out_dist,
+                                                       uint32_t* __restrict__ out_counts, uint32_t* __restrict__ out_status,
+                                                       unsigned char* lds, int lane) {
   const uint32_t dpad = g.dpad;
   float* q_lds = (float*)lds;
   float* pf_scratch = q_lds + dpad;
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 3))) void
 #ifdef FVDB_GRAPH_STAMPS
   unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+  const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();
 #endif
   uint32_t rows_scored = 1, hops_done = 0;  // the entry point was scored above
   for (uint32_t layer = g.top_level + 1; layer-- > 0;) {
@@ -583,6 +585,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 3))) void
   if (lane == 0 && g.stamps) {
     t_acc[7] = __builtin_amdgcn_s_memtime() - t_begin;
     for (int i = 0; i < 8; ++i) atomicAdd(g.stamps + i, t_acc[i]);
+    if (b < 16384) {
+      const unsigned long long hw = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;
+      g.stamps[8 + 3 * b] = (t_acc[7] & 0xFFFFFFFFull) | (hw << 32) | (xcc << 60);
+      g.stamps[8 + 3 * b + 1] = r_begin;
+      g.stamps[8 + 3 * b + 2] = __builtin_amdgcn_s_memrealtime() - r_begin;
+    }
   }
 #endif
   if (lane == 0 && g.counters) {
@@ -606,6 +614,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 3))) void
       out_dist[(size_t)b * k + i] = __uint_as_float(0x7F800000u);
     }
   }
+}
+
+template <bool RH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 3))) void hnsw_search_kernel(const GraphView g, const float* __restrict__ queries,
+                                                         uint32_t B, uint32_t k, uint32_t ef_final, uint32_t cand_cap,
+                                                         uint32_t* __restrict__ visited /* [B][words] zero on entry */,
+                                                         uint32_t words, uint32_t* __restrict__ touched /* [B][tcap] */,
+                                                         uint32_t tcap, uint32_t* __restrict__ out_nodes,
+                                                         float* __restrict__ out_dist, uint32_t* __restrict__ out_counts,
+                                                         uint32_t* __restrict__ out_status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const uint32_t b = blockIdx.x;
+  if (b >= B) return;
+  hnsw_search_exact_body<RH>(g, queries, b, k, ef_final, cand_cap, visited, words, touched, tcap, out_nodes, out_dist, out_counts,
+                             out_status, lds, (int)threadIdx.x);
 }
 
 }  // namespace fvdb

@@ -75,6 +75,10 @@ def test_c1_sequential_insert_graph_and_searches_match_oracle(fv, ctx, generator
         assert np.array_equal(bits(got.distances), bits(want[1])), device
     gh.set_device_traversal(True)
     assert gh.device_fallbacks() == 0
-    if generator == "survey_mixture":  # self-match (tests/hnsw/core.rs:199-226 at this shape)
+    if generator == "survey_mixture":
+        # self-match (tests/hnsw/core.rs:199-226) at this shape: the reference's nearest-M neighbour selection (no
+        # diversity heuristic) leaves well-separated components poorly connected, so ef = 50 finds ~70 % of the stored
+        # vectors themselves on this data — the oracle, i.e. the reference's algorithm, behaves identically
         r = gh.search(x[:200], 1, 50)
-        assert np.mean(r.ids[:, 0] == ids[:200]) > 0.9
+        ro = oh.batch_search(x[:200], 1, 50)
+        assert np.array_equal(r.ids, ro[0]) and np.mean(r.ids[:, 0] == ids[:200]) > 0.5
