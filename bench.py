@@ -1,24 +1,26 @@
 #!/usr/bin/env python
 """bench.py — k-NN queries/sec at recall@10 >= 0.95 on the BASELINE.json headline workload.
 
-Workload (config.workload "c3"): 1M x 384 f32, hybrid HNSW/IVF (30 % recent -> HNSW, 70 %
-historical -> IVF-flat nlist 1024, inserted in 10K-vector chunks), batch = 1024 queries, k = 10.
-One "step" = one batch of 1024 queries through HybridIndex.search (auto-migration check, IVF
-coarse + list scan + top-k on the GPU, HNSW traversal on the host with every hop's candidate
-batch scored on the GPU, stable merge).  Query batches are resident in HBM before the timed
-region starts; results return to host memory (the reference API returns them to the caller).
+Workload (config.workload "c3"): 1M x 384 f32, hybrid HNSW/IVF (30 % recent -> HNSW, 70 % historical -> IVF-flat
+nlist 1024, inserted in 10K-vector chunks), batch = 1024 queries, k = 10.  One "step" = one batch of 1024 queries
+through HybridIndex's search (IVF coarse + list scan + top-k and the whole HNSW traversal on the GPU, the reference's
+stable merge on the host).  Query batches are resident in HBM before the timed region starts; every step's results are
+complete, in host memory, inside it (the reference API returns them to the caller).
 
   python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`:
-every rank brings its own batch of queries per step (weak scaling); IVF lists are sharded over the ranks (the
-query batches are all-gathered, every rank scans the probed lists it owns for ALL queries, the per-rank partial
-top-k are all-gathered over RCCL and merged by key on the rank that owns the query), the HNSW graph is replicated
-and each rank searches it for its own queries.
+N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per
+GPU.  IVF lists are sharded over the ranks, the graph is replicated; both exchange steps of a search run over RCCL
+inside the engine's C ABI (fvdb_comm_*, fvdb_ivf_search_sharded_begin/_end).  torch.distributed (gloo, CPU) only
+carries the 128-byte RCCL id to the ranks and implements the barrier / max-over-ranks of the contract.
+--scaling weak (default): every rank brings its own batch per step (global batch N x 1024); strong: the global batch
+stays 1024, every rank produces the results of its slice.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-"roofline" (dominant kernel = the list-scan kernel, timed with HIP events on its stream) and
-"cpu_baseline" (the CPU oracle = the reference algorithm restated, timed on this box's host cores
-on a bounded sample of the same queries; it is only the checker/baseline, never the product path).
+"roofline" — the dominant kernel (the graph traversal) against the HBM roofline, with the list scan as a second entry,
+durations measured live with HIP events on the launch streams; and "cpu_baseline" — the CPU oracle (the reference
+algorithm restated) timed on this box's host cores on a bounded sample of the same queries (checker/baseline only,
+never the product path).  --supplementary adds the two side workloads described in DESIGN.md (isotropic-384 IVF,
+sequential-insert hybrid); their outputs are committed under profiles/.
 """
 import argparse
 import json
@@ -32,6 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 DAY = 86400.0
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16
 
 
 def log(*a):
@@ -40,11 +44,11 @@ def log(*a):
 
 
 # ------------------------------------------------------------------------------------------------
-# synthetic data: latent Gaussian mixture embedded in d dims (see DESIGN.md "Synthetic data")
+# synthetic data
 # ------------------------------------------------------------------------------------------------
 class Generator:
-    """rows = (mean[c] + N(0, I_L)) @ P + ambient * N(0, I_d); means ~ spread * N(0, I_L), P: L x d orthonormal.
-    Counter-based Philox streams keyed by (seed, chunk) so any rank can regenerate any chunk."""
+    """rows = (mean[c] + N(0, I_L)) @ P + ambient * N(0, I_d); means ~ spread * N(0, I_L), P: L x d orthonormal
+    (DESIGN.md "Synthetic data").  Counter-based Philox streams keyed by (seed, chunk): any rank regenerates any chunk."""
 
     def __init__(self, d=384, latent=32, n_comp=4096, spread=1.5, ambient=0.02, seed=1234):
         self.d, self.L, self.n_comp, self.ambient, self.seed = d, latent, n_comp, ambient, seed
@@ -63,6 +67,20 @@ class Generator:
         return np.ascontiguousarray(x, dtype=np.float32)
 
 
+class IsotropicGenerator:
+    """SURVEY §8d's generator: 4096 component means ~ N(0, I_d), row = mean + 0.35 N(0, I_d)."""
+
+    def __init__(self, d=384, n_comp=4096, sigma=0.35, seed=1234):
+        self.d, self.n_comp, self.sigma, self.seed = d, n_comp, sigma, seed
+        r = np.random.Generator(np.random.Philox(key=seed))
+        self.means = r.standard_normal((n_comp, d), dtype=np.float32)
+
+    def rows(self, n, stream):
+        r = np.random.Generator(np.random.Philox(key=self.seed + 1000003 * (stream + 1)))
+        comp = r.integers(0, self.n_comp, n)
+        return np.ascontiguousarray(self.means[comp] + np.float32(self.sigma) * r.standard_normal((n, self.d), dtype=np.float32))
+
+
 def usable_cpus():
     """CPUs this process may use: min(affinity, cgroup quota) — the GPU box shows 256 and grants 16."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -79,13 +97,25 @@ def recall_at_k(found_ids, found_cnt, exact_ids, k):
     hits = 0
     for b in range(found_ids.shape[0]):
         hits += len(set(found_ids[b, : found_cnt[b]].tolist()) & set(exact_ids[b, :k].tolist()))
-    return hits / (k * found_ids.shape[0])
+    return hits / (k * max(found_ids.shape[0], 1))
+
+
+def exact_ground_truth(fv, ctx, x, ids, queries, k):
+    """Flat f32 scan on the GPU (exact k-NN)."""
+    N, d = x.shape
+    flat = fv.DeviceIVF(ctx, d, 1)
+    flat.set_centroids(np.zeros((1, d), np.float32))
+    for c in range(0, N, 200_000):
+        flat.add_assigned(x[c:c + 200_000], ids[c:c + 200_000], np.zeros(min(200_000, N - c), np.uint32))
+    out = [flat.search_all(q, k)[0] for q in queries]
+    flat.close()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n-vectors", dest="n", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=384)
@@ -97,19 +127,26 @@ def main():
     ap.add_argument("--recent-frac", type=float, default=0.3)
     ap.add_argument("--recall-target", type=float, default=0.95)
     ap.add_argument("--train-sample", type=int, default=100_000)
-    ap.add_argument("--query-batches", type=int, default=4)
+    ap.add_argument("--query-batches", type=int, default=16, help="distinct query batches cycled through the steps")
+    ap.add_argument("--select-batches", type=int, default=4,
+                    help="batches the operating point is chosen on; the rest are held out and must confirm it")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hnsw-traversal", choices=["device", "host"], default="device",
                     help="device: the layered walk runs on the GPU (one launch per batch); host: on the host with one "
                          "candidate-scoring launch per hop (the north_star's split).  Identical results.")
-    ap.add_argument("--compare-host-walk", type=int, default=5, help="extra steps timed with the host walk (0 = skip)")
+    ap.add_argument("--compare-host-walk", type=int, default=3, help="extra steps timed with the host walk (0 = skip)")
     ap.add_argument("--parts", choices=["both", "recent", "historical"], default="both",
                     help="development aid: time only the HNSW or only the IVF part of the hybrid search (recall is then meaningless)")
     ap.add_argument("--in-flight", type=int, default=4,
                     help="batches in flight during the timed region (1 = each step collected before the next is enqueued)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="multi-GPU: see the module docstring")
+    ap.add_argument("--transport", choices=["rccl", "hosted"], default=os.environ.get("FVDB_TRANSPORT", "rccl"),
+                    help="hosted: exchanges carried over torch.distributed on host buffers (several ranks on ONE GPU)")
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--spread", type=float, default=1.5)
+    ap.add_argument("--supplementary", action="store_true",
+                    help="also run the isotropic-384 IVF workload and the sequential-insert 100K hybrid (minutes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,33 +156,23 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    dist = None
-    torch = None
+    dist = torch = None
     force_sharded = os.environ.get("FVDB_FORCE_SHARDED") == "1"  # exercise the multi-GPU code path on one rank
-    if world > 1 or force_sharded:
-        import torch  # noqa: F811  (first, so this process uses one HIP runtime)
+    if world > 1:
+        import torch  # noqa: F811
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        backend = os.environ.get("FVDB_DIST_BACKEND", "nccl")  # "gloo": rehearsal of several ranks on ONE GPU
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, rank=rank, world_size=world)
-        # RCCL prints a version banner on stdout at its first collective; stdout must carry ONE JSON line, so the
-        # first collective runs with fd 1 pointed at stderr
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.barrier()
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+        # rendezvous / barrier / max-over-ranks only: the data path's collectives are RCCL calls inside the engine
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import fvdb_import
     fv = fvdb_import.load()
+    sh = fv.sharded
+    if world > 1 and args.transport == "rccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)  # counting devices does not initialise the GPU
+    elif world > 1:
+        local_rank = 0  # hosted rehearsal: every rank on the box's one GPU
 
     N, d, B, k = args.n, args.dim, args.batch, args.k
     now = 1000 * DAY
@@ -160,9 +187,13 @@ def main():
     is_recent = r.random(N) < args.recent_frac
     ts = np.where(is_recent, now - 1 * DAY, now - 30 * DAY)
     nb = max(1, args.query_batches)
-    # every rank brings its own query batches (weak scaling: world x B queries per step)
-    queries = [gen.rows(B, stream=10_000_000 + 1000 * rank + i) for i in range(nb)]
-    log(f"data: {N} x {d} generated in {time.time() - t_setup:.1f}s; recent={int(is_recent.sum())}")
+    nsel = max(1, min(args.select_batches, nb))
+    strong = world > 1 and args.scaling == "strong"
+    mode = sh.STRONG if strong else sh.WEAK
+    # weak: every rank brings its own query batches; strong: one stream of global batches, identical on every rank
+    qrank = 0 if strong else rank
+    queries = [gen.rows(B, stream=10_000_000 + 1000 * qrank + i) for i in range(nb)]
+    log(f"data: {N} x {d} generated in {time.time() - t_setup:.1f}s; recent={int(is_recent.sum())}; {nb} query batches")
 
     ctx_ivf = fv.Context(local_rank)
     ctx_hnsw = fv.Context(local_rank)
@@ -175,60 +206,82 @@ def main():
 
     # ---- placement: single GPU = everything; multi GPU = lists sharded, HNSW replicated ----
     t0 = time.time()
-    sharded = None
+    sharded = comm = None
     if world == 1 and not force_sharded:
         hyb.bulk_insert(ids, x, ts, now)
     else:
-        from fabstir_vectordb_amd import sharded as sh
-        sharded = sh.ShardedHybrid(fv, hyb, rank, world, dist, torch)
-        sharded.bulk_insert(ids, x, ts, now)
+        # RCCL prints a version banner on stdout when it initialises; stdout must carry ONE JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            comm = (sh.Comm.hosted(ctx_ivf, dist, torch) if (args.transport == "hosted" and world > 1)
+                    else sh.Comm.rccl(ctx_ivf, dist, torch))
+            sharded = sh.ShardedHybrid(hyb, comm)
+            sharded.bulk_insert(ids, x, ts, now)
+            if dist is not None:
+                dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     log(f"index build (HNSW bulk graph {hyb.recent_count()} nodes + IVF {hyb.historical_count()} rows): "
         f"{time.time() - t0:.1f}s")
 
     # ---- exact ground truth on the GPU (flat scan of all N rows) ----
     t0 = time.time()
-    flat = fv.DeviceIVF(ctx_ivf, d, 1)
-    flat.set_centroids(np.zeros((1, d), np.float32))
-    for c in range(0, N, 200_000):
-        flat.add_assigned(x[c:c + 200_000], ids[c:c + 200_000], np.zeros(min(200_000, N - c), np.uint32))
-    exact = [flat.search_all(q, k)[0] for q in queries]
-    flat.close()
-    log(f"exact ground truth: {time.time() - t0:.1f}s")
+    exact = exact_ground_truth(fv, ctx_ivf, x, ids, queries, k)
+    log(f"exact ground truth ({nb} batches): {time.time() - t0:.1f}s")
 
-    qdev = [ctx_ivf.upload(q) for q in queries] if sharded is None else [sharded.upload_queries(q) for q in queries]
+    qdev = [ctx_ivf.upload(q) for q in queries]
     hyb.hnsw().set_device_traversal(args.hnsw_traversal == "device")
+    # rows of the step this rank produces (strong: its slice of the global batch)
+    per = -(-B // world)
+    lo, hi = (min(B, rank * per), min(B, (rank + 1) * per)) if strong else (0, B)
 
     def run(i, nprobe, ef):
         if sharded is not None:
-            return sharded.search_dev(qdev[i % nb], B, k, now, ef, nprobe)
+            return sharded.search_dev(qdev[i % nb], B, k, ef, nprobe, mode)
         return hyb.search_dev(qdev[i % nb], B, k, now=now, hnsw_ef=ef, ivf_n_probe=nprobe, dim=d)
 
-    def mean_over_ranks(v):
+    def mean_over_ranks(v, weight=1.0):
         """Same value on every rank (decisions taken on it keep the ranks' collectives in lockstep)."""
-        if dist is None or world == 1:
+        if dist is None:
             return float(v)
-        t = torch.tensor([float(v)], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor([float(v) * weight, weight], dtype=torch.float64)
         dist.all_reduce(t)
-        return float(t.item()) / world
+        return float(t[0].item() / max(t[1].item(), 1e-30))
 
-    # ---- operating point: smallest (nprobe, ef) of the sweep with recall@k >= target ----
+    def recall_of(i, nprobe, ef):
+        res = run(i, nprobe, ef)
+        return mean_over_ranks(recall_at_k(res.ids, res.counts, exact[i % nb][lo:hi], k), weight=float(hi - lo))
+
+    # ---- operating point: the smallest (nprobe, ef) of the sweep whose recall@k reaches the target on the selection
+    # batches AND on the held-out batches ----
     sweep = []
     nprobe, ef = args.nprobe, args.ef
+    held_out = None
     if nprobe == 0 or ef == 0:
         chosen = None
         for e_ in ([ef] if ef else [50, 100, 200]):
             for p_ in ([nprobe] if nprobe else [8, 16, 24, 32, 48, 64, 96, 128]):
                 p_ = min(p_, args.nlist)
-                res = run(0, p_, e_)
-                rec = mean_over_ranks(recall_at_k(res.ids, res.counts, exact[0], k))
-                if rec >= args.recall_target:  # confirm on every query batch before accepting
-                    rec = mean_over_ranks(np.mean([recall_at_k(res.ids, res.counts, exact[0], k)] +
-                                                  [recall_at_k(*(lambda r_: (r_.ids, r_.counts))(run(i, p_, e_)), exact[i], k)
-                                                   for i in range(1, nb)]))
-                sweep.append({"nprobe": p_, "ef": e_, "recall": round(rec, 4)})
-                log(f"sweep nprobe={p_} ef={e_}: recall@{k}={rec:.4f}")
-                if rec >= args.recall_target and chosen is None:
-                    chosen = (p_, e_)
+                rec = recall_of(0, p_, e_)
+                entry = {"nprobe": p_, "ef": e_}
+                if rec >= args.recall_target:
+                    rec = float(np.mean([rec] + [recall_of(i, p_, e_) for i in range(1, nsel)]))
+                    if rec >= args.recall_target and nb > nsel:
+                        ho = float(np.mean([recall_of(i, p_, e_) for i in range(nsel, nb)]))
+                        entry["recall_held_out"] = round(ho, 4)
+                        if ho >= args.recall_target:
+                            held_out = ho
+                            chosen = (p_, e_)
+                    elif rec >= args.recall_target:
+                        chosen = (p_, e_)
+                entry["recall"] = round(rec, 4)
+                sweep.append(entry)
+                log(f"sweep nprobe={p_} ef={e_}: recall@{k}={rec:.4f}" + (f" held-out {entry['recall_held_out']:.4f}" if "recall_held_out" in entry else ""))
+                if chosen:
                     break
             if chosen:
                 break
@@ -242,12 +295,11 @@ def main():
     depth = max(1, min(args.in_flight, 8))
     kw = dict(now=now, hnsw_ef=ef, ivf_n_probe=nprobe, dim=d, search_recent=args.parts != "historical",
               search_historical=args.parts != "recent")
-
     if sharded is None:
         begin = lambda slot, i: hyb.search_dev_begin(slot, qdev[i % nb], B, k, **kw)  # noqa: E731
         end = hyb.search_dev_end
-    else:  # every rank runs the same sequence of begin/end calls (each holds one collective)
-        begin = lambda slot, i: sharded.search_dev_begin(slot, qdev[i % nb], B, k, now, ef, nprobe)  # noqa: E731
+    else:  # every rank runs the same sequence of begin/end calls (each step holds two collectives)
+        begin = lambda slot, i: sharded.search_dev_begin(slot, qdev[i % nb], B, k, ef, nprobe, mode)  # noqa: E731
         end = sharded.search_dev_end
 
     def pipelined(nsteps):
@@ -269,10 +321,14 @@ def main():
             t_end += time.perf_counter() - ta
         return res, t_begin, t_end
 
+    def sync_all():
+        ctx_ivf.device_synchronize()  # every stream of the device (one per batch in flight) = torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
     ctx_ivf.set_profiling(2)      # on before the warm-up: the first profiled search creates events etc.
     ctx_hnsw.set_profiling(2)     # HIP events around the traversal kernel (its own stream)
-    # the multi-GPU path has more lazily initialised parts (RCCL channels, torch's staging buffers): extra warm-up
-    for i in range(args.warmup if sharded is None else max(args.warmup, 12)):
+    for i in range(args.warmup if sharded is None else max(args.warmup, 8)):
         run(i, nprobe, ef)
     if depth > 1:
         pipelined(max(args.warmup, 2 * depth))  # every slot has its stream, buffers and traversal state before timing
@@ -280,173 +336,183 @@ def main():
     hyb.ivf_device_stage_times()  # reset accumulators
     hnsw = hyb.hnsw()
     hnsw.graph_kernel_times()
-    if dist is not None:
-        # a barrier is followed, a few searches later, by a one-off stall of tens of ms (seen with RCCL on one rank
-        # as well): take it outside the timed region — barrier, a few untimed searches, barrier again
-        dist.barrier()
-        torch.cuda.synchronize()
-        for i in range(6):
-            run(i, nprobe, ef)
-        hyb.ivf_device_stage_times()
-        hnsw.graph_kernel_times()
     evals0, hops0 = hnsw.dist_evals(), hnsw.hops()
-    if dist is not None:
-        dist.barrier()
-        torch.cuda.synchronize()
-    ctx_ivf.synchronize()
-    ctx_hnsw.synchronize()
+    sync_all()
     t0 = time.perf_counter()
     last = None
+    t_begin = t_end = 0.0
     if depth == 1:
         for i in range(args.steps):
             last = run(i, nprobe, ef)
     else:
-        # up to `depth` batches in flight: step i is enqueued (graph walk on its own stream, IVF chain behind the
-        # previous batch's on the IVF stream) before step i - depth + 1 is collected and merged on the host.  Every
-        # step's results are complete, on the host, inside the timed region.
+        # up to `depth` batches in flight: step i is enqueued (graph walk on its own stream, IVF chain on the slot's)
+        # before step i - depth + 1 is collected and merged on the host.  Every step's results are complete, on the
+        # host, inside the timed region.
         last, t_begin, t_end = pipelined(args.steps)
-    t_loop = time.perf_counter() - t0
-    ctx_ivf.synchronize()
-    ctx_hnsw.synchronize()
+    ctx_ivf.device_synchronize()
+    t_local = time.perf_counter() - t0
     if dist is not None:
-        torch.cuda.synchronize()
-        t_sync = time.perf_counter() - t0
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    log(f"timed region done: {elapsed:.3f}s" + (f" (loop {t_loop:.4f}s, synced {t_sync:.4f}s)" if dist is not None else ""))
+    log(f"timed region done: {elapsed:.3f}s (this rank {t_local:.3f}s)")
     if depth > 1:
         log(f"host time per step: enqueue {t_begin / args.steps * 1e3:.3f} ms, collect+merge (incl. waiting) {t_end / args.steps * 1e3:.3f} ms")
     if dist is not None:
-        tt = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    graph_ms_sum, graph_launches, graph_rows, graph_hops = hnsw.graph_kernel_times()
-    # per-stage timing of the IVF chain: a few more steps, one batch at a time (the events of one chain would be
-    # overwritten by the next while several batches are in flight)
+    hnsw.graph_kernel_times()  # launches of the timed region overlap each other: per-launch durations are taken below
+    # per-kernel / per-stage timing: a few more steps, ONE batch at a time (with several batches in flight the launches
+    # of different batches overlap and stretch each other, and one chain's events would be overwritten by the next)
     hyb.ivf_device_stage_times()
-    for i in range(5):
+    n_solo = 8
+    for i in range(n_solo):
         run(i, nprobe, ef)
+    graph_ms_sum, graph_launches, graph_rows, graph_hops = hnsw.graph_kernel_times()
     ctx_ivf.set_profiling(0)
     ctx_hnsw.set_profiling(0)
-    hnsw.graph_kernel_times()
     n_prof, stage = hyb.ivf_device_stage_times()
     stats = hyb.ivf_device_last_stats()
-    evals, hops = hnsw.dist_evals() - evals0, hnsw.hops() - hops0
 
     # the same workload with the other traversal mode (reported next to the headline value)
     other = None
     if args.compare_host_walk > 0 and world == 1:
         hnsw.set_device_traversal(args.hnsw_traversal != "device")
         run(0, nprobe, ef)
-        ctx_ivf.synchronize()
+        ctx_ivf.device_synchronize()
         t1 = time.perf_counter()
         for i in range(args.compare_host_walk):
             run(i, nprobe, ef)
-        ctx_ivf.synchronize()
+        ctx_ivf.device_synchronize()
         dt = (time.perf_counter() - t1) / args.compare_host_walk
         other = {"hnsw_traversal": "host" if args.hnsw_traversal == "device" else "device",
                  "value": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "steps": args.compare_host_walk}
         hnsw.set_device_traversal(args.hnsw_traversal == "device")
         log(f"other traversal mode ({other['hnsw_traversal']}): {other['ms_per_step']} ms/step, {other['value']:.0f} QPS")
 
-    recs = []
-    for i in range(nb):
-        res = run(i, nprobe, ef)
-        recs.append(recall_at_k(res.ids, res.counts, exact[i], k))
-    recall = mean_over_ranks(np.mean(recs))
-    qps = world * B * args.steps / elapsed  # every rank completed B queries per step
+    recall = float(np.mean([recall_of(i, nprobe, ef) for i in range(nb)]))
+    global_batch = B if strong else world * B
+    qps = global_batch * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     log(f"{args.steps} steps: {ms_per_step:.3f} ms/step, {qps:.0f} QPS, recall@{k}={recall:.4f}")
 
-    # ---- roofline of the list scan (the HBM-bound kernel of the path) ----
-    # ALGORITHMIC bytes per launch = sum over queries of (rows in its probed lists) x d x 4 (section 8d's
-    # nprobe*(N/nlist)*d*s per query, measured rather than averaged).  The kernel that does this work is the
-    # matrix-core filter (scan_mfma_kernel) when the matrix-core path runs, else scan_topk_kernel; its duration is
-    # measured live with HIP events on its launch stream.
-    mfma_path = stage.get("mfma_filter_kernel", 0.0) > 0.0
-    scan_ms = (stage["mfma_filter_kernel"] if mfma_path else stage["fine_scan"]) / max(n_prof, 1)
-    alg_bytes = stats["rows_scanned"] * d * 4  # rows each query's probed lists hold x row bytes
-    achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    phys_bytes = stats["list_rows_touched"] * d * (2 if mfma_path else 4)  # every probed list read once (fp16 mirror)
-    graph_ms = graph_ms_sum / max(graph_launches, 1)
-    if args.hnsw_traversal == "device":
-        evals, hops = graph_rows, graph_hops
-    gather_bytes = (evals / max(args.steps, 1)) * d * 4  # rows scored per step x row bytes
-    roofline = {
-        "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-        "frac": round(achieved / 8000.0, 4), "traffic": None,
-        "kernel": ("fvdb::scan_mfma_kernel<2, 1, 0> (IVF list scan: fp16 MFMA filter over every probed row)" if mfma_path
-                   else "fvdb::scan_topk_kernel<16, 1, 1> (IVF list scan, exact)"),
-        "kernel_ms": round(scan_ms, 4),
-        "algorithmic_bytes_per_launch": int(alg_bytes),
-        "rows_scanned_per_query": round(stats["rows_scanned"] / B, 1),
-        "physical_lower_bound_bytes_per_launch": int(phys_bytes),
-        "physical_lower_bound_GBps": round(phys_bytes / (scan_ms * 1e-3) / 1e9, 1) if scan_ms > 0 else 0.0,
-        "physical_lower_bound_frac_of_hbm_peak": round(phys_bytes / (scan_ms * 1e-3) / 1e9 / 8000.0, 4) if scan_ms > 0 else 0.0,
-        "pair_dims_per_s": round(stats["rows_scanned"] * d / (scan_ms * 1e-3), 1) if scan_ms > 0 else 0.0,
-        "note": "queries probing the same list share one read of it (32 per pass), so algorithmic bytes/s exceed the "
-                "HBM peak; the physical lower bound is every probed list streamed once per launch, see DESIGN.md",
-        "stage_ms": {k_: round(v / max(n_prof, 1), 4) for k_, v in stage.items()},
-        "graph_traversal_kernel": {
-            "kernel": "fvdb::hnsw_search_kernel<true> (one wavefront per query, whole traversal on the GPU)",
-            "kernel_ms": round(graph_ms, 4), "launches_timed": graph_launches,
-            "rows_scored_per_query": round(evals / max(args.steps, 1) / B, 1),
-            "gathered_GBps": round(gather_bytes / (graph_ms * 1e-3) / 1e9, 1) if graph_ms > 0 else 0.0,
-            "note": "latency-bound pointer chase (pop -> adjacency -> visited -> rows -> heaps per hop); it runs "
-                    "concurrently with the IVF chain on its own stream and is the longer of the two"},
-        "hnsw": {"hops_per_step": round(hops / args.steps, 1), "dist_evals_per_query": round(evals / args.steps / B, 1)},
-    }
-
-    # HBM-side traffic of that kernel from PMC counters (FETCH_SIZE / WRITE_SIZE are collected in their own
-    # rocprofv3 passes by tools/pmc_traffic.sh for this same command and committed under profiles/;
-    # gfx950: FETCH_SIZE counts wide streaming reads at half their bytes => doubled, see MI355X_MICROARCH.md)
-    try:
-        pmj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        pm = pmj["list_scan"]
-        if N == 1_000_000 and nprobe == pmj.get("nprobe") and world == 1 and mfma_path:
-            roofline["traffic"] = int((2 * pm["FETCH_SIZE_KB_avg"] + pm["WRITE_SIZE_KB_avg"]) * 1024)
-            roofline["traffic_note"] = "bytes per launch beyond L2 (Infinity Cache + HBM), 2*FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json"
-            if scan_ms > 0:
-                roofline["traffic_GBps"] = round(roofline["traffic"] / (scan_ms * 1e-3) / 1e9, 1)
-                roofline["traffic_frac_of_hbm_peak"] = round(roofline["traffic"] / (scan_ms * 1e-3) / 1e9 / 8000.0, 4)
-            roofline["pmc"] = {
-                "source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes of this command)",
-                "mfma_busy_frac_of_busy_simd_cycles": {
-                    name: round(pmj[name]["SQ_VALU_MFMA_BUSY_CYCLES_avg"] / (4.0 * pmj[name]["SQ_BUSY_CU_CYCLES_avg"]), 4)
-                    for name in ("coarse_gemm", "threshold_pass", "list_scan") if name in pmj},
-            }
-    except Exception:
-        pass
+    roofline = build_roofline(args, d, B, hi - lo, world, stage, n_prof, stats, graph_ms_sum, graph_launches, graph_rows,
+                              graph_hops, ms_per_step)
 
     # ---- CPU baseline: the oracle (reference algorithm restated) on the same structures ----
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
-        cpu = cpu_baseline(fv, hyb, sharded, x, ids, is_recent, ts, now, queries[0], last if nb == 1 else run(0, nprobe, ef),
-                           k, nprobe, ef, args)
+        cpu = cpu_baseline(fv, hyb, x, ids, is_recent, now, queries[0], run(0, nprobe, ef), k, nprobe, ef, args)
+
+    supplementary = None
+    if args.supplementary and world == 1:
+        supplementary = run_supplementary(fv, ctx_ivf, args)
 
     if rank == 0:
+        if world == 1:
+            par = "1 gpu"
+        elif strong:
+            par = (f"ivf lists sharded x{world}: every rank scans its lists for the same {B} queries, all-to-all of the partial "
+                   f"top-k, rank r merges and returns slice r; hnsw graph replicated, each rank walks its slice")
+        else:
+            par = (f"ivf lists sharded x{world}: all-gather of queries + probe lists, every rank scans its lists for all "
+                   f"{world}x{B} queries, all-to-all of the partial top-k; hnsw graph replicated, each rank walks its own {B} queries")
         out = {
             "metric": "k-NN queries/sec at recall@10>=0.95, 1Mx384 f32",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "c3: 1M x 384 f32 hybrid HNSW/IVF (10K-vector chunks), batch 1024, k 10",
-                       "n_vectors": N, "dim": d, "batch": B, "global_batch": world * B, "k": k, "recent_frac_hnsw": args.recent_frac,
-                       "nlist": args.nlist, "nprobe": nprobe, "hnsw_ef": ef, "hnsw_M": 16, "hnsw_M0": 32, "hnsw_traversal": args.hnsw_traversal, "batches_in_flight": depth,
+                       "n_vectors": N, "dim": d, "batch": B, "global_batch": global_batch, "k": k, "recent_frac_hnsw": args.recent_frac,
+                       "nlist": args.nlist, "nprobe": nprobe, "hnsw_ef": ef, "hnsw_M": 16, "hnsw_M0": 32,
+                       "hnsw_graph": "bulk_build: every layer member linked to its exact nearest M (M0) members",
+                       "hnsw_traversal": args.hnsw_traversal, "batches_in_flight": depth, "query_batches": nb,
                        "other_traversal_mode": other, "hnsw_device_fallbacks": hnsw.device_fallbacks(),
-                       "recall_at_10": round(recall, 4), "recall_target": args.recall_target, "sweep": sweep,
+                       "recall_at_10": round(recall, 4), "recall_target": args.recall_target,
+                       "recall_held_out_batches": None if held_out is None else round(held_out, 4), "sweep": sweep,
                        "generator": f"gaussian mixture: 4096 comps, means {args.spread}*N(0,I) in a rank-{args.latent} latent space, "
                                     f"unit within-comp sigma, orthonormal embedding into {d}-d + 0.02 ambient noise",
-                       "parallelism": "1 gpu" if world == 1 else f"ivf lists sharded x{world} (each rank scans its lists for all {world}x{B} queries) + all-gather of queries and of partial top-k; hnsw graph replicated, each rank searches its own {B} queries"},
+                       "transport": None if world == 1 and not force_sharded else args.transport,
+                       "parallelism": par},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if supplementary is not None:
+            out["supplementary"] = supplementary
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(fv, hyb, sharded, x, ids, is_recent, ts, now, q0, gpu_res, k, nprobe, ef, args):
+def build_roofline(args, d, B, rows_out, world, stage, n_prof, stats, graph_ms_sum, graph_launches, graph_rows, graph_hops,
+                   ms_per_step):
+    """frac = max(physical bytes / HBM peak, useful flops / MFMA peak) / kernel time, per launch, for the dominant
+    kernel (the graph traversal) and for the list scan.  Durations: HIP events on the launch stream, one batch at a
+    time.  SURVEY §8d's per-query algorithmic GB/s is kept as a separately named field (queries probing one list
+    share one read of it, so that figure is not a fraction of anything)."""
+    n_prof = max(n_prof, 1)
+    # ---- graph traversal: every scored row is gathered once per query (no sharing), plus the adjacency rows ----
+    gl = max(graph_launches, 1)
+    graph_ms = graph_ms_sum / gl
+    rows_pl, hops_pl = graph_rows / gl, graph_hops / gl
+    g_bytes = rows_pl * d * 4 + hops_pl * 33 * 4
+    g_ach = g_bytes / (graph_ms * 1e-3) / 1e9 if graph_ms > 0 else 0.0
+    # ---- list scan ----
+    mfma_path = stage.get("mfma_filter_kernel", 0.0) > 0.0
+    scan_ms = (stage["mfma_filter_kernel"] if mfma_path else stage["fine_scan"]) / n_prof
+    phys_bytes = stats["list_rows_touched"] * d * (2 if mfma_path else 4)  # every probed list once (fp16 mirror)
+    flops = 2.0 * stats["rows_scanned"] * d                                  # one multiply-add per (row, query, dim)
+    t_bytes = phys_bytes / (HBM_PEAK_GBPS * 1e9)
+    t_flops = flops / (MFMA_F16_PEAK_TFLOPS * 1e12) if mfma_path else 0.0
+    s_frac = max(t_bytes, t_flops) / (scan_ms * 1e-3) if scan_ms > 0 else 0.0
+    alg_bytes = stats["rows_scanned"] * d * 4
+    roofline = {
+        "bound": "hbm", "achieved": round(g_ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(g_ach / HBM_PEAK_GBPS, 4), "traffic": None,
+        "kernel": "fvdb::hnsw_search_fast_kernel<3, 16> (HNSW: whole layered traversal, one wavefront per query) — the longest "
+                  "kernel of a step; gather-latency bound",
+        "kernel_ms": round(graph_ms, 4), "launches_timed": graph_launches,
+        "bytes_per_launch": int(g_bytes), "rows_scored_per_query": round(rows_pl / max(rows_out, 1), 1),
+        "hops_per_query": round(hops_pl / max(rows_out, 1), 1),
+        "note": "bytes = rows scored x d x 4 (each gathered once per query; nothing is shared between queries) + one 132-byte "
+                "adjacency row per hop; duration from HIP events on the launch stream, one batch at a time",
+        "list_scan": {
+            "bound": "hbm" if t_bytes >= t_flops else "mfma",
+            "kernel": ("fvdb::scan_mfma_kernel (IVF list scan: fp16 MFMA filter over every probed row)" if mfma_path
+                       else "fvdb::scan_topk_kernel (IVF list scan, exact)"),
+            "kernel_ms": round(scan_ms, 4),
+            "physical_lower_bound_bytes": int(phys_bytes), "useful_flops": int(flops),
+            "achieved": round(phys_bytes / (scan_ms * 1e-3) / 1e9, 1) if scan_ms > 0 else 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(s_frac, 4),
+            "algorithmic_bytes_per_launch_survey_8d": int(alg_bytes),
+            "algorithmic_GBps_survey_8d": round(alg_bytes / (scan_ms * 1e-3) / 1e9, 1) if scan_ms > 0 else 0.0,
+            "rows_scanned_per_query": round(stats["rows_scanned"] / max(B * (world if args.scaling == "weak" else 1), 1), 1),
+            "note": "physical lower bound = every probed list streamed once per launch in fp16; SURVEY 8d's per-query "
+                    "algorithmic bytes are shared by the queries probing a list, hence reported, not priced",
+        },
+        "stage_ms": {k_: round(v / n_prof, 4) for k_, v in stage.items()},
+    }
+    assert 0.0 <= roofline["frac"] <= 1.0 and 0.0 <= roofline["list_scan"]["frac"] <= 1.0, "roofline fraction out of range"
+    # HBM-side traffic from PMC counters (FETCH_SIZE / WRITE_SIZE in their own rocprofv3 passes, tools/pmc_traffic.sh;
+    # gfx950: FETCH_SIZE counts wide streaming reads at half their bytes => doubled, see MI355X_MICROARCH.md)
+    try:
+        pmj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        if args.n == pmj.get("n_vectors") and world == 1:
+            g = pmj.get("graph_traversal")
+            if g:
+                roofline["traffic"] = int((2 * g["FETCH_SIZE_KB_avg"] + g["WRITE_SIZE_KB_avg"]) * 1024)
+                roofline["traffic_note"] = "bytes per launch beyond L2 (Infinity Cache + HBM), 2*FETCH_SIZE+WRITE_SIZE, profiles/r02_pmc_traffic.json"
+            ls = pmj.get("list_scan")
+            if ls and mfma_path:
+                roofline["list_scan"]["traffic"] = int((2 * ls["FETCH_SIZE_KB_avg"] + ls["WRITE_SIZE_KB_avg"]) * 1024)
+            tot = (roofline.get("traffic") or 0) + (roofline["list_scan"].get("traffic") or 0)
+            assert tot / (ms_per_step * 1e-3) / 1e9 <= HBM_PEAK_GBPS, "PMC traffic per step exceeds the HBM peak"
+    except (OSError, KeyError, ValueError):
+        pass
+    return roofline
+
+
+def cpu_baseline(fv, hyb, x, ids, is_recent, now, q0, gpu_res, k, nprobe, ef, args):
     """Times the CPU oracle on a bounded sample and checks the GPU results against it."""
     import oracle as orc
     orc.build()
@@ -464,7 +530,7 @@ def cpu_baseline(fv, hyb, sharded, x, ids, is_recent, ts, now, q0, gpu_res, k, n
     setup_s = time.time() - t0
     ns = min(args.cpu_sample, q0.shape[0])
     t0 = time.perf_counter()
-    oi1, od1, oc1 = o.batch_search(q0[: max(8, ns // 8)], k, now=now, hnsw_ef=ef, ivf_n_probe=nprobe, threads=1)
+    o.batch_search(q0[: max(8, ns // 8)], k, now=now, hnsw_ef=ef, ivf_n_probe=nprobe, threads=1)
     t1 = time.perf_counter() - t0
     t0 = time.perf_counter()
     oi, od, oc = o.batch_search(q0[:ns], k, now=now, hnsw_ef=ef, ivf_n_probe=nprobe, threads=threads)
@@ -476,6 +542,88 @@ def cpu_baseline(fv, hyb, sharded, x, ids, is_recent, ts, now, q0, gpu_res, k, n
     return {"value": round(ns / tall, 2), "unit": "queries/s", "cores": threads, "kind": "port",
             "sample": f"{ns} queries of the first batch, same index structures and (nprobe, ef); one query per thread",
             "single_thread_value": round(max(8, ns // 8) / t1, 2), "gpu_matches_oracle_on_sample": same}
+
+
+def run_supplementary(fv, ctx, args):
+    """Two side workloads, so the headline does not rest on the bulk-built graph and the latent-32 generator alone:
+    (1) SURVEY §8d's isotropic 384-d mixture, IVF part only (700K rows, nlist 1024): QPS and recall per nprobe;
+    (2) a 100K hybrid whose HNSW part (30K nodes) is built by the reference's SEQUENTIAL insert: QPS and recall."""
+    out = {}
+    d, B, k = args.dim, args.batch, args.k
+    # ---- (1) isotropic IVF ----
+    gen = IsotropicGenerator(d=d)
+    n = 700_000
+    x = np.concatenate([gen.rows(10_000, s) for s in range(n // 10_000)])
+    ids = np.arange(n, dtype=np.uint64)
+    qs = [gen.rows(B, 10_000_000 + i) for i in range(4)]
+    ivf = fv.IVFIndex(ctx, n_clusters=args.nlist, n_probe=32, train_size=100_000, max_iterations=25, seed=7)
+    ivf.train(x[np.random.Generator(np.random.Philox(key=5)).choice(n, 100_000, replace=False)])
+    ivf.batch_insert(ids, x)
+    exact = exact_ground_truth(fv, ctx, x, ids, qs, k)
+    qd = [ctx.upload(q) for q in qs]
+    oi, od, oc = ctx.alloc(B * k * 8), ctx.alloc(B * k * 4), ctx.alloc(B * 4)
+    rows = []
+    for p in (8, 16, 32, 64):
+        rec = float(np.mean([recall_at_k(*(lambda r_: (r_.ids, r_.counts))(ivf.search(qs[i], k, p)), exact[i], k) for i in range(4)]))
+        h = ivf._dev()
+        for _ in range(3):
+            ctx.check(ctx.lib.fvdb_ivf_search_dev(h, qd[0], B, k, p, oi, od, oc, None))
+        ctx.synchronize()
+        ctx.timer_start()
+        R = 20
+        for j in range(R):
+            ctx.check(ctx.lib.fvdb_ivf_search_dev(h, qd[j % 4], B, k, p, oi, od, oc, None))
+        ms = ctx.timer_stop_ms() / R
+        rows.append({"nprobe": p, "recall_at_10": round(rec, 4), "ms_per_batch": round(ms, 4), "queries_per_s": round(B / ms * 1e3, 1)})
+        log(f"supplementary isotropic IVF nprobe={p}: recall {rec:.4f}, {ms:.3f} ms/batch")
+    out["isotropic_384_ivf_700k"] = {"generator": "SURVEY 8d: 4096 comps, means N(0,I_384), sigma 0.35", "nlist": args.nlist,
+                                     "batch": B, "one_batch_at_a_time": rows,
+                                     "scan_fallbacks": int(ivf_scan_fallbacks(ctx, ivf))}
+    del ivf, x
+    # ---- (2) sequential-insert hybrid, 100K ----
+    gen = Generator(d=d, latent=args.latent, spread=args.spread)
+    n = 100_000
+    x = np.concatenate([gen.rows(10_000, s) for s in range(n // 10_000)])
+    ids = np.arange(n, dtype=np.uint64)
+    now = 1000 * DAY
+    is_recent = np.random.Generator(np.random.Philox(key=99)).random(n) < args.recent_frac
+    hyb = fv.HybridIndex(ctx, n_clusters=256, n_probe=32, train_size=50_000, max_iterations=25, ivf_seed=7, hnsw_seed=11)
+    hyb.initialize(x[:50_000])
+    t0 = time.time()
+    hist = ~is_recent
+    hyb.ivf().batch_insert(ids[hist], x[hist])  # the lists; then the graph, node by node, the reference's way
+    h = hyb.hnsw()
+    h.batch_insert(ids[is_recent], x[is_recent])
+    build_s = time.time() - t0
+    qs = [gen.rows(B, 10_000_000 + i) for i in range(4)]
+    exact = exact_ground_truth(fv, ctx, x, ids, qs, k)
+    rows = []
+    qd = [ctx.upload(q) for q in qs]
+    for p, e in ((16, 50), (32, 50), (32, 100), (64, 200)):
+        recs = [recall_at_k(*(lambda r_: (r_.ids, r_.counts))(hyb.search(qs[i], k, now=now, hnsw_ef=e, ivf_n_probe=p)), exact[i], k)
+                for i in range(4)]
+        for _ in range(2):
+            hyb.search_dev(qd[0], B, k, now=now, hnsw_ef=e, ivf_n_probe=p, dim=d)
+        t1 = time.perf_counter()
+        R = 10
+        for j in range(R):
+            hyb.search_dev(qd[j % 4], B, k, now=now, hnsw_ef=e, ivf_n_probe=p, dim=d)
+        ms = (time.perf_counter() - t1) / R * 1e3
+        rows.append({"nprobe": p, "ef": e, "recall_at_10": round(float(np.mean(recs)), 4), "ms_per_batch": round(ms, 4),
+                     "queries_per_s": round(B / ms * 1e3, 1)})
+        log(f"supplementary sequential-insert hybrid nprobe={p} ef={e}: recall {np.mean(recs):.4f}, {ms:.3f} ms/batch")
+    out["hybrid_100k_sequential_insert"] = {"hnsw_nodes": int(is_recent.sum()), "build_s": round(build_s, 1),
+                                            "hnsw_build": "HNSWIndex::insert one node at a time (src/hnsw/core.rs:226-378), "
+                                                          "every hop's candidates scored on the GPU",
+                                            "one_batch_at_a_time": rows}
+    return out
+
+
+def ivf_scan_fallbacks(ctx, ivf):
+    import ctypes as C
+    v = C.c_uint64(0)
+    ctx.lib.fvdb_ivf_scan_fallbacks(ivf._dev(), C.byref(v))
+    return v.value
 
 
 if __name__ == "__main__":

@@ -28,6 +28,7 @@ SIGNATURES = {
     "fvdb_ctx_create": (i32, [i32, C.POINTER(vp)]),
     "fvdb_ctx_destroy": (None, [vp]),
     "fvdb_ctx_synchronize": (i32, [vp]),
+    "fvdb_device_synchronize": (i32, [vp]),
     "fvdb_ctx_stream": (vp, [vp]),
     "fvdb_last_error": (C.c_char_p, [vp]),
     "fvdb_dev_alloc": (i32, [vp, sz, C.POINTER(vp)]),

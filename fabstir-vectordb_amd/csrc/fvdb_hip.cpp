@@ -878,6 +878,11 @@ int fvdb_ctx_synchronize(fvdb_ctx* ctx) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FVDB_OK;
 }
+int fvdb_device_synchronize(fvdb_ctx* ctx) {
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  return FVDB_OK;
+}
 void* fvdb_ctx_stream(fvdb_ctx* ctx) { return (void*)ctx->stream; }
 const char* fvdb_last_error(fvdb_ctx* ctx) {
   if (!ctx) return "null context";

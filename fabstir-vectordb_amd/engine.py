@@ -106,6 +106,10 @@ class Context:
         except Exception:
             pass
 
+    def device_synchronize(self):
+        """Wait for every stream of this context's device (the engine keeps one stream per batch in flight)."""
+        self.check(self.lib.fvdb_device_synchronize(self.h))
+
     def synchronize(self):
         self.check(self.lib.fvdb_ctx_synchronize(self.h))
 

@@ -74,6 +74,7 @@ typedef struct fvdb_store fvdb_store; /* row-major vector store for gathered can
 int fvdb_ctx_create(int device, fvdb_ctx** out);
 void fvdb_ctx_destroy(fvdb_ctx* ctx);
 int fvdb_ctx_synchronize(fvdb_ctx* ctx);
+int fvdb_device_synchronize(fvdb_ctx* ctx); /* every stream of ctx's device (hipDeviceSynchronize) */
 int fvdb_ctx_device(fvdb_ctx* ctx); /* the device ordinal the context was created on */
 void* fvdb_ctx_stream(fvdb_ctx* ctx);          /* hipStream_t, for callers that interleave work */
 const char* fvdb_last_error(fvdb_ctx* ctx);    /* message of the last failing call on ctx */
