@@ -218,6 +218,7 @@ struct fvdb_ivf : IvfScratch {
   std::mutex mu;            // list table upload, lease bookkeeping, AUTO-mode counters
   std::condition_variable lease_cv;
   std::atomic<IvfScratch*> last_set{nullptr};  // scratch set of the most recent search (diagnostic entry points)
+  std::atomic<fvdb_ctx*> last_ctx{nullptr};    // and the context (stream) it ran on
   fvdb_ctx* ctx = nullptr;
   uint32_t d = 0, dpad = 0, d4 = 0, nlist = 0;
   bool trained = false;
@@ -436,17 +437,17 @@ int run_coarse(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, uint3
     const float* cpad = ivf->d == ivf->dpad ? ivf->d_centroids_rm.as<float>() : ivf->d_cent_pad.as<float>();
     HIPCHK(ctx, S.s_qnorm.ensure((size_t)B * 4));
     HIPCHK(ctx, S.s_A.ensure((size_t)B * nlist * 4));
-    if (ctx->profiling) (void)hipEventRecord(S.sev[0], ctx->stream);
+    if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[0], ctx->stream);
     hipLaunchKernelGGL(row_sqnorm_wave_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, qpad, ivf->dpad, ivf->dpad, B,
                        S.s_qnorm.as<float>());
     const uint32_t waves = cdiv(B, 32) * cdiv(nlist, 64);
     hipLaunchKernelGGL(coarse_gemm_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, ctx->stream, qpad, cpad,
                        S.s_qnorm.as<float>(), ivf->d_cnorm.as<float>(), B, nlist, ivf->dpad, S.s_A.as<float>());
-    if (ctx->profiling) (void)hipEventRecord(S.sev[1], ctx->stream);
+    if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[1], ctx->stream);
     hipLaunchKernelGGL(coarse_select_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, S.s_A.as<float>(), qpad, cpad,
                        S.s_qnorm.as<float>(), ivf->d_cnmax.as<float>(), B, nlist, ivf->d, ivf->dpad, 64u, kc,
                        out_probes, out_dist, ivf->s_fallbacks.as<uint32_t>());
-    if (ctx->profiling) (void)hipEventRecord(S.sev[2], ctx->stream);
+    if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[2], ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     return FVDB_OK;
   }
@@ -466,9 +467,9 @@ int run_coarse(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, uint3
                S.s_ceoff.as<uint32_t>(), S.s_cioff.as<uint32_t>(), S.s_entries.as<uint2>(), scal + 0,
                scal + 1, qpad, ivf->dpad, segb, kc, 1, maxsegs, S.s_cpart.as<uint2>(),
                cdiv(cblocks, segb) * cdiv(B, Q)};
-  if (ctx->profiling) (void)hipEventRecord(S.sev[0], ctx->stream);
+  if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[0], ctx->stream);
   launch_scan(ctx, s, ROLE_COARSE);
-  if (ctx->profiling) (void)hipEventRecord(S.sev[1], ctx->stream);
+  if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[1], ctx->stream);
   MergeArgs m{};
   m.pool = ivf->cpool.view();
   m.lists = ListTable{ivf->c_off.as<uint32_t>(), ivf->c_blocks.as<uint32_t>(), 1};
@@ -483,7 +484,7 @@ int run_coarse(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, uint3
   m.out_probes = out_probes;
   m.out_dist = out_dist;
   launch_merge(ctx, m);
-  if (ctx->profiling) (void)hipEventRecord(S.sev[2], ctx->stream);
+  if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[2], ctx->stream);
   HIPCHK(ctx, hipGetLastError());
   return FVDB_OK;
 }
@@ -528,13 +529,13 @@ int run_fine_exact(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, u
                      (unsigned long long*)(scal + 4));
   hipLaunchKernelGGL(plan_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, probes, n, np,
                      S.s_eoff.as<uint32_t>(), S.s_fill.as<uint32_t>(), S.s_entries.as<uint2>());
-  if (ctx->profiling && events) (void)hipEventRecord(S.sev[3], ctx->stream);
+  if (ivf->ctx->profiling && events) (void)hipEventRecord(S.sev[3], ctx->stream);
   ScanLaunch s{ivf->pool.view(), ivf->t_off.as<uint32_t>(), ivf->t_blocks.as<uint32_t>(), nlist,
                S.s_eoff.as<uint32_t>(), S.s_ioff.as<uint32_t>(), S.s_entries.as<uint2>(), scal + 2,
                scal + 3, qpad, ivf->dpad, segb, k, np, maxsegs, S.s_part.as<uint2>()};
   s.f16 = ivf->f16;
   launch_scan(ctx, s, role);
-  if (ctx->profiling && events) (void)hipEventRecord(S.sev[4], ctx->stream);
+  if (ivf->ctx->profiling && events) (void)hipEventRecord(S.sev[4], ctx->stream);
   MergeArgs m{};
   m.pool = ivf->pool.view();
   m.lists = ListTable{ivf->t_off.as<uint32_t>(), ivf->t_blocks.as<uint32_t>(), nlist};
@@ -551,7 +552,7 @@ int run_fine_exact(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, u
   m.out_counts = out_counts;
   m.out_keys = out_keys;
   launch_merge(ctx, m);
-  if (ctx->profiling && events) (void)hipEventRecord(S.sev[5], ctx->stream);
+  if (ivf->ctx->profiling && events) (void)hipEventRecord(S.sev[5], ctx->stream);
   HIPCHK(ctx, hipGetLastError());
   return FVDB_OK;
 }
@@ -612,7 +613,7 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   uint32_t* scal = S.s_scalars.as<uint32_t>();
   const uint32_t grid = (uint32_t)ctx->num_cus * (uint32_t)std::max(1, wgs_env);
   const ListTable lists{ivf->t_off.as<uint32_t>(), ivf->t_blocks.as<uint32_t>(), nlist};
-  if (ctx->profiling) (void)hipEventRecord(S.sev[3], ctx->stream);
+  if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[3], ctx->stream);
 
   hipLaunchKernelGGL(prep_queries_kernel, dim3(cdiv(B + 1, 4)), dim3(256), 0, ctx->stream, qpad, B, ivf->dpad,
                      (_Float16*)S.s_qh.p, S.s_qn2.as<float>(), S.s_cnt.as<uint32_t>(), nlist,
@@ -665,10 +666,10 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   // B. filter over all probed lists
   plan(probes, B * np, np, segb, (unsigned long long*)(scal + 4));
   a.segb = segb;
-  if (ctx->profiling) (void)hipEventRecord(S.sev[6], ctx->stream);
+  if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[6], ctx->stream);
   launch_mfma<0>(ctx, a, M, half_rows, grid);
-  if (ctx->profiling) (void)hipEventRecord(S.sev[7], ctx->stream);
-  if (ctx->profiling) (void)hipEventRecord(S.sev[4], ctx->stream);
+  if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[7], ctx->stream);
+  if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[4], ctx->stream);
   S.pend_filter = true;
 
   // C. select
@@ -737,7 +738,7 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   fm.qlist = v.fail_list;
   fm.nq = v.nfail;
   launch_merge(ctx, fm);
-  if (ctx->profiling) (void)hipEventRecord(S.sev[5], ctx->stream);
+  if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[5], ctx->stream);
   // the rescan counter, for AUTO's hit-rate watch (run_fine): a 4-byte copy into pinned memory, nobody waits for it
   {
     std::lock_guard<std::mutex> lk(ivf->mu);
@@ -783,8 +784,8 @@ int run_fine(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, uint32_
 int finish_profile(fvdb_ivf* ivf, const Env& E, bool coarse, bool fine) {
   fvdb_ctx* ctx = E.ctx;
   IvfScratch& S = *E.S;
-  if (!ctx->profiling) return FVDB_OK;
-  if (ctx->profiling == 2 && !S.collecting) {  // deferred: remember what to fold in later
+  if (!ivf->ctx->profiling) return FVDB_OK;
+  if (ivf->ctx->profiling == 2 && !S.collecting) {  // deferred: remember what to fold in later
     S.pend_coarse = coarse;
     S.pend_fine = fine;
     S.pending_profile = true;
@@ -1365,7 +1366,7 @@ static int search_common(fvdb_ivf* ivf, const Env& E, const float* q_dev, uint32
   int rc = upload_table(ivf);
   if (rc) return rc;
   std::lock_guard<std::mutex> enq(S.enq);  // one search's launches go in as a block
-  if (ctx->profiling)
+  if (ivf->ctx->profiling)
     for (auto& e : S.sev)
       if (!e) (void)hipEventCreate(&e);
   const uint32_t step = sub_batch(ivf, B, k, np);
@@ -1379,10 +1380,10 @@ static int search_common(fvdb_ivf* ivf, const Env& E, const float* q_dev, uint32
     if (all) {
       hipLaunchKernelGGL(probes_all_kernel, dim3(cdiv((uint64_t)b * np, 256)), dim3(256), 0, ctx->stream, b, np,
                          S.s_probes.as<uint32_t>());
-      if (ctx->profiling) (void)hipEventRecord(S.sev[2], ctx->stream);
+      if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[2], ctx->stream);
     } else if (given_probes) {
       probes = given_probes + (size_t)o * np;
-      if (ctx->profiling) {  // no coarse stage in this call: zero-length stage intervals
+      if (ivf->ctx->profiling) {  // no coarse stage in this call: zero-length stage intervals
         (void)hipEventRecord(S.sev[0], ctx->stream);
         (void)hipEventRecord(S.sev[1], ctx->stream);
         (void)hipEventRecord(S.sev[2], ctx->stream);
@@ -1400,6 +1401,7 @@ static int search_common(fvdb_ivf* ivf, const Env& E, const float* q_dev, uint32
     if (rc) return rc;
   }
   ivf->last_set.store(E.S);
+  ivf->last_ctx.store(E.ctx);
   return FVDB_OK;
 }
 
@@ -1571,7 +1573,7 @@ int fvdb_ivf_coarse(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t nprobe, 
     const float* qpad = nullptr;
     int r = padded_queries(ivf, L.E, S.s_in.as<float>(), B, &qpad);
     if (r) return r;
-    if (ctx->profiling)
+    if (ivf->ctx->profiling)
       for (auto& e : S.sev)
         if (!e) (void)hipEventCreate(&e);
     r = run_coarse(ivf, L.E, qpad, B, np, S.s_probes.as<uint32_t>(), S.s_cdist.as<float>());
@@ -1688,11 +1690,13 @@ int fvdb_ivf_last_stats(fvdb_ivf* ivf, fvdb_search_stats* out) {
 }
 
 int fvdb_ivf_profile_collect(fvdb_ivf* ivf) {
-  if (!ivf->pending_profile) return FVDB_OK;
-  ivf->collecting = true;
-  int rc = finish_profile(ivf, Env{ivf->ctx, ivf}, ivf->pend_coarse, ivf->pend_fine);
-  ivf->collecting = false;
-  ivf->pending_profile = false;
+  IvfScratch* S = ivf->last_set.load();  // the most recent search, whichever scratch set and stream it used
+  fvdb_ctx* c = ivf->last_ctx.load();
+  if (!S || !c || !S->pending_profile) return FVDB_OK;
+  S->collecting = true;
+  int rc = finish_profile(ivf, Env{c, S}, S->pend_coarse, S->pend_fine);
+  S->collecting = false;
+  S->pending_profile = false;
   return rc;
 }
 

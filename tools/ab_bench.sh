@@ -1,13 +1,14 @@
 #!/bin/bash
-# A/B whole-bench runs of library variants (fabstir-vectordb_amd/lib_variants/libfvdb_hip_<name>.so): the host mirror links
-# lib/libfvdb_hip.so by rpath, so the file itself is swapped and put back
-cd $GRAFT_REPO_ROOT
-L=fabstir-vectordb_amd/lib/libfvdb_hip.so
-cp $L /tmp/libfvdb_hip_orig.so
-mkdir -p gpurun_out
-for v in orig "$@" orig "$@"; do
-  if [ $v = orig ]; then cp /tmp/libfvdb_hip_orig.so $L; else cp fabstir-vectordb_amd/lib_variants/libfvdb_hip_$v.so $L; fi
-  timeout -k 10 300 python bench.py --no-cpu-baseline --compare-host-walk 0 --nprobe 32 --ef 50 > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.log || { cp /tmp/libfvdb_hip_orig.so $L; exit 1; }
-  echo "== $v: $(python -c "import json,sys; d=json.load(open('gpurun_out/ab_$v.json')); print(d['value'], d['ms_per_step'], d.get('graph_traversal_kernel', d.get('roofline',{})).get('avg_ms', ''))")"
+# A/B of the whole bench under environment variants (dev aid).  usage: ab_bench.sh "<extra bench flags>" name=ENV=VAL[,ENV=VAL] ...
+mkdir -p gpurun_out/ab
+EXTRA="$1"; shift
+for spec in "$@"; do
+  name=${spec%%=*}; envs=$(echo "${spec#*=}" | tr ',' ' ')
+  env $envs python bench.py --steps 100 --warmup 3 --nprobe 32 --ef 50 --no-cpu-baseline --compare-host-walk 0 --query-batches 8 $EXTRA > gpurun_out/ab/$name.json 2> gpurun_out/ab/$name.log
+  python - <<PY
+import json
+j=json.load(open("gpurun_out/ab/$name.json"))
+r=j["roofline"]
+print("$name", j["value"], "q/s", j["ms_per_step"], "ms/step | graph", r["kernel_ms"], "ms | stages", r["stage_ms"])
+PY
 done
-cp /tmp/libfvdb_hip_orig.so $L

@@ -3,7 +3,7 @@
 #   FETCH_SIZE / WRITE_SIZE   bytes beyond L2 (gfx950: FETCH_SIZE counts wide streaming reads at half their bytes)
 #   SQ_VALU_MFMA_BUSY_CYCLES  matrix-core busy cycles, against SQ_BUSY_CU_CYCLES / GRBM_GUI_ACTIVE
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline --compare-host-walk 0 --nprobe 32 --ef 50"
+ARGS="--steps 20 --warmup 2 --no-cpu-baseline --compare-host-walk 0 --nprobe 32 --ef 50 --query-batches 8"
 rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma gpurun_out/pmc_busy
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py $ARGS > gpurun_out/pmc_bench.json 2> gpurun_out/pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py $ARGS > /dev/null 2>&1
@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --outp
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d gpurun_out/pmc_busy -- python3 bench.py $ARGS > /dev/null 2> gpurun_out/pmc_busy.log
 python3 - <<PY
 import csv, glob, collections, json
-names = {"scan_mfma_kernel<2, 1, 0>": "list_scan", "scan_mfma_kernel<2, 1, 1>": "threshold_pass", "hnsw_search_kernel": "hnsw_search",
+names = {"scan_mfma_kernel<2, 1, 0>": "list_scan", "scan_mfma_kernel<2, 1, 1>": "threshold_pass", "hnsw_search_fast_kernel": "graph_traversal",
          "coarse_gemm_kernel": "coarse_gemm", "coarse_select_kernel": "coarse_select", "select_kernel<": "select"}
 out = {}
 for tag in ("fetch", "write", "mfma", "busy"):
@@ -28,6 +28,7 @@ for tag in ("fetch", "write", "mfma", "busy"):
 try:
     b = json.loads(open("gpurun_out/pmc_bench.json").read().strip().splitlines()[-1])
     out["nprobe"] = b["config"]["nprobe"]
+    out["n_vectors"] = b["config"]["n_vectors"]
     out["command"] = "python3 bench.py $ARGS"
 except Exception as e:
     out["nprobe"] = None
