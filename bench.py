@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--compare-host-walk", type=int, default=3, help="extra steps timed with the host walk (0 = skip)")
     ap.add_argument("--parts", choices=["both", "recent", "historical"], default="both",
                     help="development aid: time only the HNSW or only the IVF part of the hybrid search (recall is then meaningless)")
-    ap.add_argument("--in-flight", type=int, default=4,
+    ap.add_argument("--in-flight", type=int, default=8,
                     help="batches in flight during the timed region (1 = each step collected before the next is enqueued)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="multi-GPU: see the module docstring")
     ap.add_argument("--transport", choices=["rccl", "hosted"], default=os.environ.get("FVDB_TRANSPORT", "rccl"),
@@ -292,7 +292,7 @@ def main():
     log(f"operating point: nprobe={nprobe} ef={ef}")
 
     # ---- timed region ----
-    depth = max(1, min(args.in_flight, 8))
+    depth = max(1, min(args.in_flight, 16))
     kw = dict(now=now, hnsw_ef=ef, ivf_n_probe=nprobe, dim=d, search_recent=args.parts != "historical",
               search_historical=args.parts != "recent")
     if sharded is None:
@@ -361,6 +361,17 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # host share of a step: collect + translate + merge of batches whose GPU work is already complete
+    host_collect_ms = None
+    if depth > 1:
+        for i in range(depth):
+            begin(i, i)
+        sync_all()
+        th = time.perf_counter()
+        for i in range(depth):
+            end(i)
+        host_collect_ms = (time.perf_counter() - th) / depth * 1e3
+        log(f"host collect+merge with the GPU work already done: {host_collect_ms:.3f} ms per step")
     hnsw.graph_kernel_times()  # launches of the timed region overlap each other: per-launch durations are taken below
     # per-kernel / per-stage timing: a few more steps, ONE batch at a time (with several batches in flight the launches
     # of different batches overlap and stretch each other, and one chain's events would be overwritten by the next)
@@ -427,7 +438,9 @@ def main():
                        "nlist": args.nlist, "nprobe": nprobe, "hnsw_ef": ef, "hnsw_M": 16, "hnsw_M0": 32,
                        "hnsw_graph": "bulk_build: every layer member linked to its exact nearest M (M0) members",
                        "hnsw_traversal": args.hnsw_traversal, "batches_in_flight": depth, "query_batches": nb,
+                       "host_collect_merge_ms_per_step": None if host_collect_ms is None else round(host_collect_ms, 4),
                        "other_traversal_mode": other, "hnsw_device_fallbacks": hnsw.device_fallbacks(),
+                       "ivf_scan_fallbacks": int(ivf_scan_fallbacks(ctx_ivf, hyb.ivf())),
                        "recall_at_10": round(recall, 4), "recall_target": args.recall_target,
                        "recall_held_out_batches": None if held_out is None else round(held_out, 4), "sweep": sweep,
                        "generator": f"gaussian mixture: 4096 comps, means {args.spread}*N(0,I) in a rank-{args.latent} latent space, "

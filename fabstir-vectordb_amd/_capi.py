@@ -139,6 +139,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make -C fabstir-vectordb_amd` "
             "(or __graft_entry__.build()).  There is no CPU fallback.")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # see fvdb_ctx_create: one hardware queue per stream in flight
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI and the build disagree

@@ -208,8 +208,8 @@ struct IvfScratch {
 };
 
 struct fvdb_ivf : IvfScratch {
-  static constexpr uint32_t kSlots = 8;
-  IvfScratch spare[kSlots - 1];  // slots 1..7
+  static constexpr uint32_t kSlots = 16;
+  IvfScratch spare[kSlots - 1];  // slots 1..15
   // leased sets for blocking searches called from several host threads: each has its own stream (a private context)
   static constexpr uint32_t kLeases = 8;
   IvfScratch lease_set[kLeases];
@@ -285,9 +285,9 @@ struct fvdb_graph {
   DBuf d_level, d_deleted, d_slot_of, d_slot_start, d_adj, d_adj0;
   uint32_t stride0 = 0;
   DBuf s_q, d_counters;
-  static constexpr uint32_t kSlots = 8;  // batches that may be in flight at once, each on its own stream
+  static constexpr uint32_t kSlots = 16;  // batches that may be in flight at once, each on its own stream
   DBuf s_visited[kSlots], s_touched[kSlots];
-  uint32_t vis_B[kSlots] = {0, 0, 0, 0, 0, 0, 0, 0}, vis_words = 0, vis_tcap = 0;
+  uint32_t vis_B[kSlots] = {}, vis_words = 0, vis_tcap = 0, vis_stride = 0;
   bool uploaded = false;
   // profiling: HIP events around the last launches of the traversal kernel (ring of 64)
   std::vector<uint8_t> h_deleted;  // host copy of the flags: searches skip the per-neighbour flag load when none is set
@@ -618,8 +618,6 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   hipLaunchKernelGGL(prep_queries_kernel, dim3(cdiv(B + 1, 4)), dim3(256), 0, ctx->stream, qpad, B, ivf->dpad,
                      (_Float16*)S.s_qh.p, S.s_qn2.as<float>(), S.s_cnt.as<uint32_t>(), nlist,
                      S.s_scnt.as<uint32_t>(), S.s_mslots.as<uint32_t>());
-  hipLaunchKernelGGL(first_probe_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, probes, B, np,
-                     ivf->t_len.as<uint32_t>(), 256u, S.s_pa.as<uint32_t>());
   auto plan = [&](const uint32_t* pr, uint32_t n, uint32_t npp, uint32_t sb, unsigned long long* stats) {
     // cnt[] is zero on entry: cleared by prep_queries_kernel for the first plan, by plan_scan_kernel for the second
     hipLaunchKernelGGL(plan_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, pr, n, S.s_cnt.as<uint32_t>());
@@ -654,14 +652,46 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   a.scnt = S.s_scnt.as<uint32_t>();
   a.slots = S.s_mslots.as<uint32_t>();
   a.capA = (uint32_t)std::max(1, capA_env);
+  static const int gii_env = env_u("FVDB_MFMA_GROUPS_IN_ITEM", 0);  // tuning aid / A-B
+  a.groups_in_item = gii_env ? 1u : 0u;
 
-  // A. threshold: MFMA pass over the first segment of a near list -> (k+6)-th smallest v -> thr
-  plan(S.s_pa.as<uint32_t>(), B, 1, segbA, nullptr);
-  a.segb = segbA;
-  launch_mfma<1>(ctx, a, M, half_rows, grid);
-  hipLaunchKernelGGL(threshold_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, S.s_mslots.as<uint32_t>(),
-                     S.s_pa.as<uint32_t>(), S.s_qn2.as<float>(), ivf->d_xmax.as<uint32_t>(), B, ka, ivf->dpad,
-                     x_rounded, S.s_thr.as<float>());
+  // A. threshold: the smallest v per row slot over the head of a near, well-filled list -> (k+6)-th smallest -> thr.
+  //    Direct form: one wave per query, one launch (kernels_mfma.h).  FVDB_MFMA_THRESHOLD_PASS=1 keeps the earlier
+  //    form (first_probe + plan + matrix-core MODE 1 pass + threshold_kernel) for A/B runs.
+  static const bool thr_pass = getenv("FVDB_MFMA_THRESHOLD_PASS") != nullptr;
+  if (!thr_pass) {
+    ThresholdArgs t{};
+    t.rows = a.pool_data;
+    t.pool_valid = a.pool_valid;
+    t.pool_norms = a.pool_norms;
+    t.d4 = ivf->d4;
+    t.lists = lists;
+    t.list_len = ivf->t_len.as<uint32_t>();
+    t.probes = probes;
+    t.qh = (const _Float16*)S.s_qh.p;
+    t.queries = qpad;
+    t.qn = S.s_qn2.as<float>();
+    t.xmax_bits = ivf->d_xmax.as<uint32_t>();
+    t.B = B;
+    t.np = np;
+    t.ka = ka;
+    t.dpad = ivf->dpad;
+    t.capA = a.capA;
+    t.min_rows = 256u;
+    t.rows_f16 = x_rounded;
+    t.thr = S.s_thr.as<float>();
+    if (half_rows) hipLaunchKernelGGL((threshold_direct_kernel<true>), dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, t);
+    else hipLaunchKernelGGL((threshold_direct_kernel<false>), dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, t);
+  } else {
+    hipLaunchKernelGGL(first_probe_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, probes, B, np,
+                       ivf->t_len.as<uint32_t>(), 256u, S.s_pa.as<uint32_t>());
+    plan(S.s_pa.as<uint32_t>(), B, 1, segbA, nullptr);
+    a.segb = segbA;
+    launch_mfma<1>(ctx, a, M, half_rows, grid);
+    hipLaunchKernelGGL(threshold_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, S.s_mslots.as<uint32_t>(),
+                       S.s_pa.as<uint32_t>(), S.s_qn2.as<float>(), ivf->d_xmax.as<uint32_t>(), B, ka, ivf->dpad,
+                       x_rounded, S.s_thr.as<float>());
+  }
 
   // B. filter over all probed lists
   plan(probes, B * np, np, segb, (unsigned long long*)(scal + 4));
@@ -845,6 +875,11 @@ const char* fvdb_version(void) { return "fvdb-hip 0.1 (gfx950)"; }
 int fvdb_ctx_create(int device, fvdb_ctx** out) {
   if (!out) return FVDB_E_INVALID;
   *out = nullptr;
+  // Batches in flight run on streams of their own (two per batch); the HIP runtime multiplexes streams onto
+  // GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue run one after the other.
+  // Ask for 16 unless the host application chose a value; this only takes effect if HIP has not been initialised
+  // yet in this process (measured: 8 batches in flight, traversal only, 0.42 -> 0.27 ms per 1024-query step).
+  (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return FVDB_E_HIP;
   fvdb_ctx* ctx = new (std::nothrow) fvdb_ctx();
@@ -2372,18 +2407,29 @@ int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const
   // visited-log capacity per query (FVDB_GRAPH_TCAP: test hook that forces the overflow -> host-walk fallback)
   const uint32_t words = (g->n + 31) / 32;
   const uint32_t tcap = getenv("FVDB_GRAPH_TCAP") ? std::max(1, atoi(getenv("FVDB_GRAPH_TCAP"))) : 8192;
-  if (words != g->vis_words || tcap != g->vis_tcap) {
+  // visited set per query: one byte per node while a batch's maps stay under 1 GiB (no atomics, see
+  // kernels_graph_fast.h), else one bit per node; the row stride is the same for both views
+  static const bool no_bytes = getenv("FVDB_GRAPH_BITMAP") != nullptr;  // tuning aid / A-B (byte map: ~2.5 % faster, 8x the memory)
+  const uint32_t vbytes = ((g->n + 63) / 64) * 64;
+  const bool bytemap = !no_bytes && (uint64_t)vbytes * std::max<uint32_t>(B, 1024) <= (1ull << 30);
+  const uint32_t vstride = bytemap ? vbytes : words * 4;
+  if (words != g->vis_words || tcap != g->vis_tcap || vstride != g->vis_stride) {
     for (auto& v : g->vis_B) v = 0;
     g->vis_words = words;
     g->vis_tcap = tcap;
+    g->vis_stride = vstride;
   }
-  if (B > g->vis_B[slot]) {  // bitmaps are left all-zero by every search: zero once
-    HIPCHK(ctx, g->s_visited[slot].ensure((size_t)B * words * 4));
+  if (B > g->vis_B[slot]) {  // the maps are left all-zero by every search: zero once
+    HIPCHK(ctx, g->s_visited[slot].ensure((size_t)B * vstride));
     HIPCHK(ctx, hipMemsetAsync(g->s_visited[slot].p, 0, g->s_visited[slot].cap, ctx->stream));
     HIPCHK(ctx, g->s_touched[slot].ensure((size_t)B * tcap * 4));
     g->vis_B[slot] = B;
   }
-  const uint32_t cand_cap = std::max<uint32_t>(1024, 8 * ef);
+  // candidate-heap slots of the exact-heap search; it holds every admitted node not yet expanded (a few hundred at
+  // ef 50), and a query that overflows it goes to the host walk.  ef <= 63 (the path that shares its LDS with the
+  // sorted-register kernel) gets the smaller heap so that more waves fit a CU.
+  static const int cand_env = getenv("FVDB_GRAPH_CAND_CAP") ? atoi(getenv("FVDB_GRAPH_CAND_CAP")) : 0;  // tuning aid
+  const uint32_t cand_cap = cand_env > 0 ? (uint32_t)cand_env : (ef <= 63 ? std::max<uint32_t>(384, 6 * ef) : std::max<uint32_t>(1024, 8 * ef));
   const size_t lds = graph_lds_bytes(s->dpad, ef, cand_cap);
   if (lds > 160 * 1024) FAIL(ctx, FVDB_E_UNSUPPORTED, "dimension / ef too large for the on-chip traversal state");
   static const bool lds_heaps = getenv("FVDB_GRAPH_LDS_HEAPS") != nullptr;  // tuning aid: lane-0 heaps for any ef
@@ -2489,15 +2535,20 @@ int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const
     int R = nb128 <= 3 ? 16 : (nb128 == 4 ? 12 : (nb128 <= 6 ? 8 : 6));  // rows per scoring round: registers R*NB*2
     if (nb128 == 3 && (fast_r == 8 || fast_r == 12)) R = fast_r;
     const uint32_t wave_lds = (uint32_t)((std::max(graph_fast_lds_bytes((uint32_t)R), lds) + 15) & ~(size_t)15);
-#define FVDB_FAST_LAUNCH(NB_, R_)                                                                                         \
+#define FVDB_FAST_LAUNCH_V(NB_, R_, BY_)                                                                                   \
   do {                                                                                                                    \
     if (4 * wave_lds > 48 * 1024)                                                                                         \
-      HIPCHK(ctx, hipFuncSetAttribute((const void*)hnsw_search_fast_kernel<NB_, R_>,                                      \
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)hnsw_search_fast_kernel<NB_, R_, BY_>,                                 \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * wave_lds)));                  \
-    hipLaunchKernelGGL((hnsw_search_fast_kernel<NB_, R_>), dim3(cdiv(B, 4)), dim3(256), 4 * wave_lds, ctx->stream, gv, qd, \
-                       B, k, ef, cand_cap, wave_lds, g->s_visited[slot].as<uint32_t>(), words,                            \
+    hipLaunchKernelGGL((hnsw_search_fast_kernel<NB_, R_, BY_>), dim3(cdiv(B, 4)), dim3(256), 4 * wave_lds, ctx->stream,   \
+                       gv, qd, B, k, ef, cand_cap, wave_lds, g->s_visited[slot].as<uint8_t>(), vstride, words,            \
                        g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev, out_counts_dev,              \
                        out_status_dev);                                                                                   \
+  } while (0)
+#define FVDB_FAST_LAUNCH(NB_, R_)                  \
+  do {                                             \
+    if (bytemap) FVDB_FAST_LAUNCH_V(NB_, R_, true); \
+    else FVDB_FAST_LAUNCH_V(NB_, R_, false);       \
   } while (0)
     if (4 * (size_t)wave_lds > 160 * 1024) FAIL(ctx, FVDB_E_UNSUPPORTED, "dimension / ef too large for the on-chip traversal state");
     switch (nb128) {
@@ -2513,14 +2564,15 @@ int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const
       case 6: FVDB_FAST_LAUNCH(6, 8); break;
       default: FVDB_FAST_LAUNCH(8, 6); break;
     }
+#undef FVDB_FAST_LAUNCH_V
 #undef FVDB_FAST_LAUNCH
   } else if (rh) {
     hipLaunchKernelGGL(hnsw_search_kernel<true>, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
-                       g->s_visited[slot].as<uint32_t>(), words, g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
+                       g->s_visited[slot].as<uint32_t>(), vstride / 4, g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
                        out_counts_dev, out_status_dev);
   } else {
     hipLaunchKernelGGL(hnsw_search_kernel<false>, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
-                       g->s_visited[slot].as<uint32_t>(), words, g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
+                       g->s_visited[slot].as<uint32_t>(), vstride / 4, g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
                        out_counts_dev, out_status_dev);
   }
   if (ev) {

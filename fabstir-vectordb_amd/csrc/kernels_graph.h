@@ -336,8 +336,8 @@ __host__ __device__ inline size_t graph_lds_bytes(uint32_t dpad, uint32_t ef, ui
 // RH: `nearest` in registers + wave-parallel heap pushes (ef <= 63); otherwise both heaps in LDS, driven by lane 0.
 template <bool RH>
 __device__ __forceinline__ void hnsw_search_exact_body(const GraphView& g, const float* __restrict__ queries, uint32_t b, uint32_t k,
-                                                       uint32_t ef_final, uint32_t cand_cap, uint32_t* __restrict__ visited,
-                                                       uint32_t words, uint32_t* __restrict__ touched, uint32_t tcap,
+                                                       uint32_t ef_final, uint32_t cand_cap, uint32_t* __restrict__ vis /* this query's bitmap, zero on entry */,
+                                                       uint32_t words, uint32_t* __restrict__ tch /* its visited log */, uint32_t tcap,
                                                        uint32_t* __restrict__ out_nodes, float* __restrict__ out_dist,
                                                        uint32_t* __restrict__ out_counts, uint32_t* __restrict__ out_status,
                                                        unsigned char* lds, int lane) {
@@ -351,8 +351,6 @@ __device__ __forceinline__ void hnsw_search_exact_body(const GraphView& g, const
   HItem* near = (HItem*)(lds + off);
   HItem* res = near + (ef_final + 2);
   HItem* cand = res + (ef_final + 1);
-  uint32_t* vis = visited + (size_t)b * words;
-  uint32_t* tch = touched + (size_t)b * tcap;
 
   for (uint32_t j = lane; j < dpad; j += 64) q_lds[j] = queries[(size_t)b * dpad + j];
   if (lane == 0) sc[2] = 0;
@@ -627,7 +625,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 3))) void
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const uint32_t b = blockIdx.x;
   if (b >= B) return;
-  hnsw_search_exact_body<RH>(g, queries, b, k, ef_final, cand_cap, visited, words, touched, tcap, out_nodes, out_dist, out_counts,
+  hnsw_search_exact_body<RH>(g, queries, b, k, ef_final, cand_cap, visited + (size_t)b * words, words, touched + (size_t)b * tcap, tcap, out_nodes, out_dist, out_counts,
                              out_status, lds, (int)threadIdx.x);
 }
 

@@ -130,10 +130,15 @@ __device__ __forceinline__ float score_round(const GraphView& g, const float2 (&
 }
 #undef FVDB_TACC
 
-template <int NB, int R>
-__global__ __launch_bounds__(256, 3) void hnsw_search_fast_kernel(const GraphView g, const float* __restrict__ queries, uint32_t B,
+// BYTES: the visited set is one BYTE per node (plain load + plain store: lanes of one instruction always hold different
+// nodes, so they never share a byte) instead of one bit per node with atomicOr — scattered integer atomics execute at
+// the memory side, one uncached request each, and 32 of them per hop were a chip-wide throughput limit.  The row of a
+// query is vstride bytes either way (the exact-heap restart uses its first `words` words as a bitmap).
+template <int NB, int R, bool BYTES>
+__global__ __launch_bounds__(256, (R <= 8 ? 4 : 3)) void hnsw_search_fast_kernel(const GraphView g, const float* __restrict__ queries, uint32_t B,
                                                               uint32_t k, uint32_t ef_final, uint32_t cand_cap, uint32_t wave_lds,
-                                                              uint32_t* __restrict__ visited /* [B][words] zero on entry */,
+                                                              uint8_t* __restrict__ visited /* [B][vstride] zero on entry */,
+                                                              uint32_t vstride,
                                                               uint32_t words, uint32_t* __restrict__ touched /* [B][tcap] */,
                                                               uint32_t tcap, uint32_t* __restrict__ out_nodes,
                                                               float* __restrict__ out_dist, uint32_t* __restrict__ out_counts,
@@ -148,7 +153,8 @@ __global__ __launch_bounds__(256, 3) void hnsw_search_fast_kernel(const GraphVie
   unsigned char* lds_f = lds_f_all + (threadIdx.x >> 6) * wave_lds;  // max(fast, exact-heap) bytes per wave
   uint32_t* pending = (uint32_t*)lds_f;
   float* stage = (float*)(pending + 64 + 16);  // two tiles
-  uint32_t* vis = visited + (size_t)b * words;
+  uint8_t* visb = visited + (size_t)b * vstride;
+  uint32_t* vis = (uint32_t*)visb;
   uint32_t* tch = touched + (size_t)b * tcap;
   const uint32_t dpad = g.dpad;
   const uint64_t lt = (1ull << lane) - 1;
@@ -189,7 +195,8 @@ __global__ __launch_bounds__(256, 3) void hnsw_search_fast_kernel(const GraphVie
     hn = ep_node;
     hd = ep_d;
     if (lane == 0) {
-      atomicOr(&vis[ep_node >> 5], 1u << (ep_node & 31));
+      if (BYTES) visb[ep_node] = 1;
+      else atomicOr(&vis[ep_node >> 5], 1u << (ep_node & 31));
       tch[0] = ep_node;
     }
     // layer 0: the adjacency row of the LIKELY next candidate (the nearest unexpanded member as things stand before
@@ -234,8 +241,13 @@ __global__ __launch_bounds__(256, 3) void hnsw_search_fast_kernel(const GraphVie
         }
         bool fresh = false, keep = false;
         if ((uint32_t)lane < cnt) {
-          const uint32_t bit = 1u << (nb & 31);
-          fresh = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;                // visited.insert (:506-507)
+          if (BYTES) {
+            fresh = visb[nb] == 0;                                          // visited.insert (:506-507)
+            if (fresh) visb[nb] = 1;
+          } else {
+            const uint32_t bit = 1u << (nb & 31);
+            fresh = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;
+          }
           keep = fresh && (g.any_deleted == 0 || g.deleted[nb] == 0);       // :511-513
         }
         const uint64_t fm = __ballot(fresh), km = __ballot(keep);
@@ -310,9 +322,12 @@ __global__ __launch_bounds__(256, 3) void hnsw_search_fast_kernel(const GraphVie
     }
     // ---- drop this layer's visited set ----
     if (nT <= tcap && status != 1) {
-      for (uint32_t i = lane; i < nT; i += 64) vis[tch[i] >> 5] = 0;
+      for (uint32_t i = lane; i < nT; i += 64) {
+        if (BYTES) visb[tch[i]] = 0;
+        else vis[tch[i] >> 5] = 0;
+      }
     } else {
-      for (uint32_t w = lane; w < words; w += 64) vis[w] = 0;
+      for (uint32_t w = lane; w < (BYTES ? vstride / 4 : words); w += 64) vis[w] = 0;
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(256, 3) void hnsw_search_fast_kernel(const GraphVie
   if (status == 2) {
     // equal distances met inside the heaps: this query is searched again, from the start, with the reference's heaps
     // restated (kernels_graph.h) — same wave, same launch; the visited bitmap was left clean above
-    hnsw_search_exact_body<true>(g, queries, b, k, ef_final, cand_cap, visited, words, touched, tcap, out_nodes, out_dist,
+    hnsw_search_exact_body<true>(g, queries, b, k, ef_final, cand_cap, vis, words, tch, tcap, out_nodes, out_dist,
                                  out_counts, out_status, lds_f, lane);
     return;
   }

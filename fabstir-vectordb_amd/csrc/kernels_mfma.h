@@ -160,6 +160,10 @@ struct MfmaScanArgs {
   // MODE 1 (only the first capA blocks of each list are looked at)
   uint32_t* slots;     // [B][64]  smallest v per row slot, order-preserving uint map (0xFFFFFFFF = empty)
   uint32_t capA;
+  // 1: the wave that draws group 0 of a list segment scans the segment for ALL its query groups, one after the other
+  // (the draws of the other groups are no-ops): the segment comes from HBM once and from this CU's XCD L2 afterwards,
+  // instead of once per group through whichever XCDs the groups' waves happen to run on
+  uint32_t groups_in_item;
 };
 
 // 16 dims of row `lane` of block `blk`: the raw 64 (f32) or 32 (fp16) bytes, requested early, and their
@@ -381,15 +385,19 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const MfmaScanArgs a) {
     const uint32_t nblk = cload(a.list_off + L + 1) - b_begin;
     const uint32_t b0 = seg * a.segb;
     const uint32_t b1 = min(b0 + a.segb, nblk);
-    const uint32_t e0 = e_begin + g * Q;
-    const uint32_t ne = min(Q, cnt - g * Q);
     if (MODE == 1 && b0 >= a.capA) continue;
-    if (M >= 2 && ne <= 16)
-      mfma_item<1, ST, MODE>(a, b_begin, b0, b1, e0, ne, seg, lane);
-    else if (M >= 4 && ne <= 32)
-      mfma_item<2, ST, MODE>(a, b_begin, b0, b1, e0, ne, seg, lane);
-    else
-      mfma_item<M, ST, MODE>(a, b_begin, b0, b1, e0, ne, seg, lane);
+    if (a.groups_in_item && g != 0) continue;
+    const uint32_t g_end = a.groups_in_item ? ngroups : g + 1;
+    for (uint32_t gg = g; gg < g_end; ++gg) {
+      const uint32_t e0 = e_begin + gg * Q;
+      const uint32_t ne = min(Q, cnt - gg * Q);
+      if (M >= 2 && ne <= 16)
+        mfma_item<1, ST, MODE>(a, b_begin, b0, b1, e0, ne, seg, lane);
+      else if (M >= 4 && ne <= 32)
+        mfma_item<2, ST, MODE>(a, b_begin, b0, b1, e0, ne, seg, lane);
+      else
+        mfma_item<M, ST, MODE>(a, b_begin, b0, b1, e0, ne, seg, lane);
+    }
   }
 }
 
@@ -473,6 +481,125 @@ __global__ __launch_bounds__(256) void threshold_kernel(const uint32_t* __restri
     }
   }
   if (lane == 0) thr_out[q] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A (direct form). One wave per query: the first `capA` blocks of a near, well-filled probed list are scored by the
+// wave itself — lane = row slot, v = |x|^2 - 2 x~.q~ from the fp16 rows and the fp16 copy of the query with
+// v_dot2_f32_f16 (exact products, f32 accumulate: inside the error budget of mfma_error_bound) — the smallest v per
+// row slot is kept in a register, the ka-th smallest of the 64 slot minima gives a_q, thr_q = a_q + 2 E_q.
+// Replaces first_probe_kernel + a plan + the MODE 1 matrix-core pass + threshold_kernel (six launches, one of them a
+// persistent whole-chip kernel of ~0.13 ms that no other batch's scan could share the chip with).
+// HALF = true: fp16 rows (the mirror of f32 rows, or fp16 storage); false: f32 rows (no mirror), f32 FMAs.
+// ---------------------------------------------------------------------------------------------
+struct ThresholdArgs {
+  const void* rows;           // pool blocks of the rows the FILTER reads (fp16 mirror / fp16 pool / f32 pool)
+  const uint64_t* pool_valid;
+  const float* pool_norms;
+  uint32_t d4;
+  ListTable lists;
+  const uint32_t* list_len;   // [nlist] rows per list on this device
+  const uint32_t* probes;     // [B][np]
+  const _Float16* qh;         // [B + 1][dpad] fp16 queries (prep_queries_kernel)
+  const float* queries;       // [B][dpad] f32 queries (HALF = false)
+  const float* qn;            // [B] |q|^2
+  const uint32_t* xmax_bits;
+  uint32_t B, np, ka, dpad, capA, min_rows;
+  int rows_f16;               // x_rounded of mfma_error_bound
+  float* thr;                 // [B]
+};
+
+template <bool HALF>
+__global__ __launch_bounds__(256) void threshold_direct_kernel(const ThresholdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t q = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (q >= a.B) return;
+  const float inf = __builtin_huge_valf();
+  // the list: the first probed one with at least min_rows rows here, else the longest probed one
+  uint32_t best_l = kInf32, best_len = 0;
+  for (uint32_t r0 = 0; r0 < a.np && best_len < a.min_rows; r0 += 64) {
+    const uint32_t r = r0 + lane;
+    uint32_t L = kInf32, len = 0;
+    if (r < a.np) {
+      L = a.probes[(size_t)q * a.np + r];
+      len = L != kInf32 ? a.list_len[L] : 0u;
+    }
+    const uint64_t big = __ballot(len >= a.min_rows);
+    if (big) {
+      const uint32_t l0 = (uint32_t)__builtin_ctzll(big);
+      best_l = rlane(L, l0);
+      best_len = rlane(len, l0);
+      break;
+    }
+    // longest so far (ties: the earlier rank, as first_probe_kernel's strict '>')
+    uint32_t ml = len, mi = (uint32_t)lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t ol = __shfl_xor(ml, o), oi = __shfl_xor(mi, o);
+      if (ol > ml || (ol == ml && oi < mi)) {
+        ml = ol;
+        mi = oi;
+      }
+    }
+    ml = rfl(ml);
+    if (ml > best_len) {
+      best_len = ml;
+      best_l = rlane(L, rfl(mi));
+    }
+  }
+  float out = inf;  // +inf: every row survives
+  if (best_l != kInf32 && best_len > 0) {
+    const uint32_t b_begin = cload(a.lists.off + best_l);
+    const uint32_t nblk = min(cload(a.lists.off + best_l + 1) - b_begin, a.capA);
+    float best = inf;
+    bool bad = false;
+    const uint32_t n8 = a.dpad >> 3;  // 8-dim chunks (dpad % 16 == 0 on this path)
+    for (uint32_t b = 0; b < nblk; ++b) {
+      const uint32_t blk = cload(a.lists.blocks + b_begin + b);
+      float dot = 0.0f;
+      if (HALF) {
+        const h8v* xp = (const h8v*)a.rows + (size_t)blk * n8 * 64 + lane;
+        const _Float16* qrow = a.qh + (size_t)q * a.dpad;
+#pragma unroll 4
+        for (uint32_t c = 0; c < n8; ++c) {
+          const h8v x = xp[(size_t)c * 64];
+          const h8v qv = cload((const h8v*)(qrow + 8 * c));  // wave-uniform: scalar loads
+          typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            dot = __builtin_amdgcn_fdot2(h2v{x[2 * t], x[2 * t + 1]}, h2v{qv[2 * t], qv[2 * t + 1]}, dot, false);
+        }
+      } else {
+        const float4* xp = (const float4*)a.rows + (size_t)blk * a.d4 * 64 + lane;
+        const float* qrow = a.queries + (size_t)q * a.dpad;
+        for (uint32_t c = 0; c < a.d4; ++c) {
+          const float4 x = xp[(size_t)c * 64];
+          const f32x4 qv = cload((const f32x4*)(qrow + 4 * c));
+          dot = __builtin_fmaf(x.x, qv[0], dot);
+          dot = __builtin_fmaf(x.y, qv[1], dot);
+          dot = __builtin_fmaf(x.z, qv[2], dot);
+          dot = __builtin_fmaf(x.w, qv[3], dot);
+        }
+      }
+      const bool live = (cload(a.pool_valid + blk) >> lane) & 1ull;
+      const float v = __builtin_fmaf(-2.0f, dot, a.pool_norms[(size_t)blk * 64 + lane]);
+      if (live) {
+        if (v != v) bad = true;  // non-finite operands: no bound from this list
+        else if (v < best) best = v;
+      }
+    }
+    if (!__ballot(bad)) {
+      uint32_t hi = best < inf ? fmap_u32(best) : kInf32, lo = (uint32_t)lane;
+      wave_sort64(hi, lo, lane);
+      const uint32_t kth = rlane(hi, a.ka - 1);
+      const float E = mfma_error_bound(__uint_as_float(*a.xmax_bits), a.qn[q], (float)a.dpad, a.rows_f16);
+      if (kth != kInf32 && kth != 0u && E < inf) {
+        const float av = funmap_u32(kth);
+        out = av + 2.0f * E + 1e-6f * fabsf(av);
+      }
+    }
+  }
+  if (lane == 0) a.thr[q] = out;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -151,7 +151,7 @@ class HNSWIndex {
   // case nothing was enqueued), end waits for it and delivers the results.
   // Device traversal split in two so that several batches can be in flight: begin enqueues the launch and the
   // result copies on the slot's own stream (slot < kSlots), end waits for that slot and finishes on the host.
-  static constexpr uint32_t kSlots = 8;
+  static constexpr uint32_t kSlots = 16;
   bool search_dev_begin(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, int* rc, uint32_t slot = 0);
   int search_dev_end(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
                      uint32_t* counts, uint32_t slot = 0);

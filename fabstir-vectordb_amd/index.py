@@ -558,7 +558,7 @@ class HybridIndex(_Base):
                                                    _ptr(ids, u64p), _ptr(ds, f32p), _ptr(cnt, u32p)))
         return SearchResults(ids, ds, cnt)
 
-    SLOTS = 8
+    SLOTS = 16
 
     def search_dev_begin(self, slot, q_dev, B, k, now=0.0, hnsw_ef=50, ivf_n_probe=10, search_recent=True,
                          search_historical=True, recent_k=0, historical_k=0, dim=None):

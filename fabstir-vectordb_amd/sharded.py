@@ -140,7 +140,7 @@ class ShardedHybrid:
     batched search with several steps in flight; per-search auto-migration is not run in this mode (nothing ages
     during a bench; the single-GPU HybridIndex keeps the reference's behaviour)."""
 
-    SLOTS = 8
+    SLOTS = 16
 
     def __init__(self, hyb, comm):
         self.hyb, self.comm = hyb, comm

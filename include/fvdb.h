@@ -174,7 +174,7 @@ int fvdb_ivf_search_dev(fvdb_ivf* ivf, const float* q_dev, uint32_t B, uint32_t 
  * with no coarse step). */
 int fvdb_ivf_search_all(fvdb_ivf* ivf, const float* q, uint32_t B, uint32_t k, uint64_t* out_ids,
                         float* out_dist, uint32_t* out_counts);
-/* Same search on the stream of context `on` (NULL = the index's own) with the slot-th (0..7) set of per-search
+/* Same search on the stream of context `on` (NULL = the index's own) with the slot-th (0..15) set of per-search
  * scratch: searches in different slots and on different contexts may be in flight together.  The index must not be
  * modified while any is.  Stage timing (profiling) is only kept for searches on the index's own context. */
 int fvdb_ivf_search_dev_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t k,
@@ -330,7 +330,7 @@ int fvdb_graph_set_deleted(fvdb_graph* g, uint32_t node, int deleted);
 int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_t k, uint32_t ef,
                           uint32_t* out_nodes_dev, float* out_dist_dev, uint32_t* out_counts_dev,
                           uint32_t* out_status_dev);
-/* Same on the stream of context `on` (NULL = the store's context), with the slot-th (0..7) set of per-batch
+/* Same on the stream of context `on` (NULL = the store's context), with the slot-th (0..15) set of per-batch
  * traversal state: searches in different slots and on different contexts may be in flight together. */
 int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t k,
                                uint32_t ef, uint32_t* out_nodes_dev, float* out_dist_dev, uint32_t* out_counts_dev,
