@@ -2425,11 +2425,11 @@ int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const
     HIPCHK(ctx, g->s_touched[slot].ensure((size_t)B * tcap * 4));
     g->vis_B[slot] = B;
   }
-  // candidate-heap slots of the exact-heap search; it holds every admitted node not yet expanded (a few hundred at
-  // ef 50), and a query that overflows it goes to the host walk.  ef <= 63 (the path that shares its LDS with the
-  // sorted-register kernel) gets the smaller heap so that more waves fit a CU.
+  // candidate-heap slots of the exact-heap search: it holds every admitted node not yet expanded; a query that
+  // overflows it goes to the host walk (data with many duplicate vectors fills it quickly, so it stays generous:
+  // at the default tile size the sorted-register kernel's LDS need is larger anyway)
   static const int cand_env = getenv("FVDB_GRAPH_CAND_CAP") ? atoi(getenv("FVDB_GRAPH_CAND_CAP")) : 0;  // tuning aid
-  const uint32_t cand_cap = cand_env > 0 ? (uint32_t)cand_env : (ef <= 63 ? std::max<uint32_t>(384, 6 * ef) : std::max<uint32_t>(1024, 8 * ef));
+  const uint32_t cand_cap = cand_env > 0 ? (uint32_t)cand_env : std::max<uint32_t>(1024, 8 * ef);
   const size_t lds = graph_lds_bytes(s->dpad, ef, cand_cap);
   if (lds > 160 * 1024) FAIL(ctx, FVDB_E_UNSUPPORTED, "dimension / ef too large for the on-chip traversal state");
   static const bool lds_heaps = getenv("FVDB_GRAPH_LDS_HEAPS") != nullptr;  // tuning aid: lane-0 heaps for any ef

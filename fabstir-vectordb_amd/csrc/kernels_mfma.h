@@ -31,6 +31,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef FVDB_MFMA_WAVES
+#define FVDB_MFMA_WAVES 2  // waves per SIMD the list-scan kernel is compiled for (3 was tried: see DESIGN.md)
+#endif
+
 namespace fvdb {
 
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
@@ -361,7 +365,7 @@ __device__ __forceinline__ void mfma_item(const MfmaScanArgs& a, const uint32_t 
 }
 
 template <int M, int ST, int MODE>
-__global__ __launch_bounds__(256) void scan_mfma_kernel(const MfmaScanArgs a) {
+__global__ __launch_bounds__(256, FVDB_MFMA_WAVES) void scan_mfma_kernel(const MfmaScanArgs a) {
   const int lane = threadIdx.x & 63;
   constexpr uint32_t Q = 16 * M;
   const uint32_t n_items = cload(a.n_items);

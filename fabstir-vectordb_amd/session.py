@@ -7,8 +7,11 @@ Kept: f64 -> f32 narrowing of inputs (bindings/node/src/utils.rs:6-8), dimension
 errors, first-call initialisation with the first <= 10 vectors (session.rs:365-378), score =
 1/(1+distance) computed in f32 (session.rs:291,328; rest.rs:653), default threshold 0.0, results in
 ascending distance, `_originalId` round trip, ids shown as `vec_<8 hex of BLAKE3>` when no original id
-exists (src/core/types.rs:32-34), metadata filters with 3x oversampling (metadata_filter.py).  Not built (out of
-scope): persistence, schema validation, native metadata types.
+exists (src/core/types.rs:32-34), metadata filters with 3x oversampling (the filter language in metadata_filter.py;
+the oversampled search itself is HybridIndex::search_with_filter of the C++ host mirror), saveToS5 /
+loadUserVectors over the chunked on-disk format (chunked.py).  Beyond SURVEY §8's rows and kept only because the
+surface tests exercise them: setSchema (metadata_schema.py), deleteByMetadata, updateMetadata.  Not built (out of
+scope): the S5 network back end, native metadata types.
 
 `blake3()` below is written from the published BLAKE3 specification (the `blake3` crate is not
 available here); it is pinned by the official known-answer vector for the empty input.
