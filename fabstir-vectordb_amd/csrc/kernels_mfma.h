@@ -283,14 +283,17 @@ __device__ __forceinline__ void mfma_item(const MfmaScanArgs& a, const uint32_t 
   };
 
   const uint32_t n = a.dpad >> 4;  // 16-dim steps per block
-  if ((n & 3) == 0) {
-    // The item is one stream of steps over (block, chunk), consumed four at a time.  Row loads run 3 steps ahead
-    // of the MFMAs and query-fragment loads 1 step ahead, every load unconditional (inactive lanes read the zero
-    // row, the tail re-requests the last step) so that the wait counts are static and the loads really overlap:
-    // HBM latency is ~1 us, a step's MFMAs ~50 ns.
+  // ring depth: rows and query fragments are requested D - 1 steps ahead of the MFMAs that consume them.  vmcnt
+  // retires loads in issue order, so a step waits for its row chunk from HBM whatever else is in flight: the only
+  // way to shorten a step is to have more steps in flight.  The 16-query form has the registers for 8.
+  constexpr int D = M == 1 ? 8 : 4;
+  if ((n & (D - 1)) == 0) {
+    // The item is one stream of steps over (block, chunk), consumed D at a time.  Every load is unconditional
+    // (inactive lanes read the zero row, the tail re-requests the last step) so that the wait counts are static and
+    // the loads really overlap: HBM latency is ~2 us under load, a step's MFMAs ~50 ns.
     const uint32_t total = (b1 - b0) * n;
-    RowChunk16<ST> ring[4];
-    h8v qf0[2][M], qf1[2][M];
+    RowChunk16<ST> ring[D];
+    h8v qf0[D][M], qf1[D][M];
     uint32_t ib = b0, ic = 0;  // next row step to request
     auto issue_row = [&](RowChunk16<ST>& dst) {
       const bool in = ib < b1;
@@ -308,26 +311,27 @@ __device__ __forceinline__ void mfma_item(const MfmaScanArgs& a, const uint32_t 
         d1[m] = *(const h8v*)(qsrc[m] + 16 * c16 + 8);
       }
     };
-    issue_row(ring[0]);
-    issue_row(ring[1]);
-    issue_row(ring[2]);
-    issue_q(0, qf0[0], qf1[0]);
-    uint32_t b = b0, cc = 0;  // step being consumed
-    for (uint32_t s = 0; s < total; s += 4) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        issue_row(ring[(u + 3) & 3]);
-        const uint32_t cn = cc + u + 1;
-        issue_q(cn == n ? 0u : cn, qf0[(u + 1) & 1], qf1[(u + 1) & 1]);
+    for (int u = 0; u < D - 1; ++u) {
+      issue_row(ring[u]);
+      issue_q((uint32_t)u, qf0[u], qf1[u]);  // n >= D
+    }
+    uint32_t b = b0, cc = 0;  // step being consumed
+    for (uint32_t s = 0; s < total; s += D) {
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        issue_row(ring[(u + D - 1) & (D - 1)]);
+        const uint32_t cn = cc + u + D - 1;  // n % D == 0 and cc % D == 0: at most one wrap
+        issue_q(cn >= n ? cn - n : cn, qf0[(u + D - 1) & (D - 1)], qf1[(u + D - 1) & (D - 1)]);
         h8v a0, a1;
         operands_a16<ST>(ring[u], a0, a1);
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf0[u & 1][m], acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf1[u & 1][m], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf0[u][m], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf1[u][m], acc[m], 0, 0, 0);
         }
       }
-      cc += 4;
+      cc += D;
       if (cc == n) {
         cc = 0;
         block_done(b, cload(a.list_blocks + b_begin + b));
