@@ -80,6 +80,8 @@ struct fvdb_comm {
   fvdb_exchange_fn fn = nullptr;    // hosted transport (tests / rehearsal): the caller moves host buffers
   void* user = nullptr;
   std::mutex mu;                    // one collective at a time per communicator, same order on every rank
+  hipEvent_t last = nullptr;        // end of the previous collective of this communicator, on whichever stream it ran
+  bool have_last = false;
   HBuf h_send, h_recv;
 };
 
@@ -102,6 +104,10 @@ int comm_exchange(fvdb_comm* c, fvdb_ctx* on, int op, const Xfer* x, int n) {
   std::lock_guard<std::mutex> lk(c->mu);
   const size_t W = (size_t)c->world;
   if (c->nccl) {
+    // steps of different slots run on different streams; the collectives of ONE communicator must not overlap on the
+    // device either, so each waits (on the device, not on the host) for the previous one to finish
+    if (!c->last) HIPCHK(on, hipEventCreateWithFlags(&c->last, hipEventDisableTiming));
+    if (c->have_last) HIPCHK(on, hipStreamWaitEvent(on->stream, c->last, 0));
     RCCLCHK(on, g_rccl.GroupStart());
     for (int i = 0; i < n; ++i) {
       if (op == XCHG_ALL_GATHER) {
@@ -114,6 +120,8 @@ int comm_exchange(fvdb_comm* c, fvdb_ctx* on, int op, const Xfer* x, int n) {
       }
     }
     RCCLCHK(on, g_rccl.GroupEnd());
+    HIPCHK(on, hipEventRecord(c->last, on->stream));
+    c->have_last = true;
     return FVDB_OK;
   }
   for (int i = 0; i < n; ++i) {
@@ -198,6 +206,7 @@ void fvdb_comm_destroy(fvdb_comm* c) {
   if (!c) return;
   (void)hipSetDevice(c->ctx->device);
   if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
+  if (c->last) (void)hipEventDestroy(c->last);
   c->h_send.release();
   c->h_recv.release();
   delete c;

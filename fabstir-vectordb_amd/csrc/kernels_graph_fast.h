@@ -34,6 +34,12 @@
 
 namespace fvdb {
 
+#ifndef FVDB_FAST_ADD_UNROLL
+#define FVDB_FAST_ADD_UNROLL 16  // LDS reads in flight ahead of the add chain (8: 1 % slower; 32: spills)
+#endif
+#ifndef FVDB_FAST_WAVES16
+#define FVDB_FAST_WAVES16 3      // waves per SIMD the 16-row form is compiled for (its LDS allows two workgroups per CU)
+#endif
 constexpr uint32_t kFastStride = 132;  // floats per staged row block: 128 products + 4 pad (lane r's reads hit 16 distinct bank quads)
 
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
@@ -92,7 +98,7 @@ __device__ __forceinline__ float score_fixed(const float* __restrict__ rows, uin
     float* cur = stage + (uint32_t)(c & 1) * tile_floats;
     if (c + 1 < NB) products(c + 1, stage + (uint32_t)((c + 1) & 1) * tile_floats);
     const float4* p = (const float4*)(cur + lrow * kFastStride);
-#pragma unroll 8
+#pragma unroll FVDB_FAST_ADD_UNROLL
     for (int i = 0; i < 32; ++i) {
       const float4 v = p[i];
       acc = acc + v.x;
@@ -135,7 +141,7 @@ __device__ __forceinline__ float score_round(const GraphView& g, const float2 (&
 // the memory side, one uncached request each, and 32 of them per hop were a chip-wide throughput limit.  The row of a
 // query is vstride bytes either way (the exact-heap restart uses its first `words` words as a bitmap).
 template <int NB, int R, bool BYTES>
-__global__ __launch_bounds__(256, (R <= 8 ? 4 : 3)) void hnsw_search_fast_kernel(const GraphView g, const float* __restrict__ queries, uint32_t B,
+__global__ __launch_bounds__(256, (R <= 8 ? 4 : (R <= 12 ? 3 : FVDB_FAST_WAVES16))) void hnsw_search_fast_kernel(const GraphView g, const float* __restrict__ queries, uint32_t B,
                                                               uint32_t k, uint32_t ef_final, uint32_t cand_cap, uint32_t wave_lds,
                                                               uint8_t* __restrict__ visited /* [B][vstride] zero on entry */,
                                                               uint32_t vstride,
