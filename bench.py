@@ -380,6 +380,13 @@ def main():
     for i in range(n_solo):
         run(i, nprobe, ef)
     graph_ms_sum, graph_launches, graph_rows, graph_hops = hnsw.graph_kernel_times()
+    # and the traversal with the card to itself (no list-scan chain beside it): the kernel's own latency-bound time
+    graph_alone_ms = None
+    if world == 1 and args.hnsw_traversal == "device":
+        for i in range(n_solo):
+            hnsw.search_dev(qdev[i % nb], B, d, k, ef)
+        ms_a, n_a, _, _ = hnsw.graph_kernel_times()
+        graph_alone_ms = ms_a / max(n_a, 1)
     ctx_ivf.set_profiling(0)
     ctx_hnsw.set_profiling(0)
     n_prof, stage = hyb.ivf_device_stage_times()
@@ -409,6 +416,9 @@ def main():
 
     roofline = build_roofline(args, d, B, hi - lo, world, stage, n_prof, stats, graph_ms_sum, graph_launches, graph_rows,
                               graph_hops, ms_per_step)
+    if graph_alone_ms:
+        roofline["kernel_ms_alone"] = round(graph_alone_ms, 4)
+        roofline["frac_alone"] = round(roofline["bytes_per_launch"] / (graph_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
 
     # ---- CPU baseline: the oracle (reference algorithm restated) on the same structures ----
     cpu = None
@@ -488,7 +498,9 @@ def build_roofline(args, d, B, rows_out, world, stage, n_prof, stats, graph_ms_s
         "bytes_per_launch": int(g_bytes), "rows_scored_per_query": round(rows_pl / max(rows_out, 1), 1),
         "hops_per_query": round(hops_pl / max(rows_out, 1), 1),
         "note": "bytes = rows scored x d x 4 (each gathered once per query; nothing is shared between queries) + one 132-byte "
-                "adjacency row per hop; duration from HIP events on the launch stream, one batch at a time",
+                "adjacency row per hop; duration from HIP events on the launch stream, one hybrid batch at a time (the list-scan "
+                "chain of the same batch runs beside it on its own stream; kernel_ms_alone / frac_alone: the traversal with the "
+                "card to itself)",
         "list_scan": {
             "bound": "hbm" if t_bytes >= t_flops else "mfma",
             "kernel": ("fvdb::scan_mfma_kernel (IVF list scan: fp16 MFMA filter over every probed row)" if mfma_path
