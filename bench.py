@@ -207,6 +207,7 @@ def main():
     # ---- placement: single GPU = everything; multi GPU = lists sharded, HNSW replicated ----
     t0 = time.time()
     sharded = comm = None
+    transport_used = None
     if world == 1 and not force_sharded:
         hyb.bulk_insert(ids, x, ts, now)
     else:
@@ -215,8 +216,11 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            comm = (sh.Comm.hosted(ctx_ivf, dist, torch) if (args.transport == "hosted" and world > 1)
-                    else sh.Comm.rccl(ctx_ivf, dist, torch))
+            if world > 1:
+                comm, transport_used = sh.bring_up(ctx_ivf, dist, torch, args.transport, log=log)
+            else:
+                comm, transport_used = sh.Comm.rccl(ctx_ivf, dist, torch), "rccl"
+                sh.self_test(comm)
             sharded = sh.ShardedHybrid(hyb, comm)
             sharded.bulk_insert(ids, x, ts, now)
             if dist is not None:
@@ -455,7 +459,7 @@ def main():
                        "recall_held_out_batches": None if held_out is None else round(held_out, 4), "sweep": sweep,
                        "generator": f"gaussian mixture: 4096 comps, means {args.spread}*N(0,I) in a rank-{args.latent} latent space, "
                                     f"unit within-comp sigma, orthonormal embedding into {d}-d + 0.02 ambient noise",
-                       "transport": None if world == 1 and not force_sharded else args.transport,
+                       "transport": None if world == 1 and not force_sharded else transport_used,
                        "parallelism": par},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -24,6 +24,7 @@
 #include "kernels_scan.h"
 #include "kernels_coarse.h"
 #include "kernels_mfma.h"
+#include "kernels_mfma_wg.h"
 #include "kernels_util.h"
 
 using namespace fvdb;
@@ -584,11 +585,20 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   // tuning aids
   static const int M_env = env_u("FVDB_MFMA_M", 2), segb_env = env_u("FVDB_MFMA_SEGB", 0),
                    segbA_env = env_u("FVDB_MFMA_SEGB_A", 1), capA_env = env_u("FVDB_MFMA_CAP_A", 8), wgs_env = env_u("FVDB_MFMA_WGS_PER_CU", 2);
-  const int M = M_env >= 4 ? 4 : (M_env >= 2 ? 2 : 1);
+  static const int wg_m_env = env_u("FVDB_MFMA_WG_M", 4);
+  int M = M_env >= 4 ? 4 : (M_env >= 2 ? 2 : 1);
+  // the workgroup form of the filter (kernels_mfma_wg.h): fp16 rows, dpad a multiple of 128, 32 or 64 queries per group
+  static const int wg_env = env_u("FVDB_MFMA_WG", 1), wg_segb_env = env_u("FVDB_MFMA_WG_SEGB", 16),
+                   wg_wgs_env = env_u("FVDB_MFMA_WG_PER_CU", 2);
+  const int wgM = wg_m_env >= 4 ? 4 : 2;
+  const bool use_wg = wg_env && M == 2 && (ivf->f16 || ivf->pool.half != nullptr) && ivf->dpad % 128 == 0 &&
+                      mfma_wg_lds_bytes(ivf->dpad, 16u * wgM) <= 64u * 1024u;
+  if (use_wg) M = wgM;
   const uint32_t Q = 16u * M;
   const uint32_t nlist = ivf->nlist, ka = k + kMfmaSlack, cmax = kMfmaCmax;
   const uint32_t segbA = std::max(1, segbA_env);
-  const uint32_t segb = segb_env > 0 ? (uint32_t)segb_env : pick_segb(ivf, B, np);
+  const uint32_t segb = use_wg ? (uint32_t)std::max(4, wg_segb_env)
+                               : (segb_env > 0 ? (uint32_t)segb_env : pick_segb(ivf, B, np));
   // partial lists of the exact rescan: same geometry as the exact scan's
   const uint32_t fsegb = pick_segb(ivf, B, np), fmaxsegs = std::max<uint32_t>(1, cdiv(ivf->max_list_blocks, fsegb));
   const uint64_t fpart = (uint64_t)B * np * fmaxsegs * k;
@@ -697,7 +707,69 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   plan(probes, B * np, np, segb, (unsigned long long*)(scal + 4));
   a.segb = segb;
   if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[6], ctx->stream);
-  launch_mfma<0>(ctx, a, M, half_rows, grid);
+  static const int stamps_env = env_u("FVDB_MFMA_STAMPS", 0);  // dev aid: per-item timeline of the workgroup filter
+  static void* stamps_buf = nullptr;
+  static int stamps_launch = 0;
+  constexpr uint32_t kStampsCap = 32768;
+  const bool stamp_now = use_wg && stamps_env && ++stamps_launch >= stamps_env && stamps_launch < stamps_env + 3;
+  if (stamp_now) {
+    if (!stamps_buf) HIPCHK(ctx, hipMalloc(&stamps_buf, (size_t)kStampsCap * 64));
+    HIPCHK(ctx, hipMemsetAsync(stamps_buf, 0, (size_t)kStampsCap * 64, ctx->stream));
+    a.stamps = (unsigned long long*)stamps_buf;
+    a.stamps_cap = kStampsCap;
+  }
+  if (use_wg) {
+    const dim3 wg_grid((uint32_t)ctx->num_cus * (uint32_t)std::max(1, wg_wgs_env));
+    if (M == 4)
+      hipLaunchKernelGGL(scan_mfma_wg_kernel<4>, wg_grid, dim3(256), mfma_wg_lds_bytes(ivf->dpad, 64), ctx->stream, a);
+    else
+      hipLaunchKernelGGL(scan_mfma_wg_kernel<2>, wg_grid, dim3(256), mfma_wg_lds_bytes(ivf->dpad, 32), ctx->stream, a);
+  } else
+    launch_mfma<0>(ctx, a, M, half_rows, grid);
+  if (stamp_now) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned long long> h((size_t)kStampsCap * 8);
+    HIPCHK(ctx, hipMemcpy(h.data(), stamps_buf, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t_min = ~0ull, t_max = 0;
+    size_t n = 0;
+    for (size_t i = 0; i < kStampsCap; ++i)
+      if (h[i * 8 + 3]) {
+        t_min = std::min(t_min, h[i * 8]);
+        t_max = std::max(t_max, h[i * 8 + 3]);
+        ++n;
+      }
+    double s_loc = 0, s_tile = 0, s_comp = 0, s_steps = 0, s_blocks = 0;
+    size_t per_xcd[16] = {0};
+    std::vector<double> per_step;
+    for (size_t i = 0; i < kStampsCap; ++i) {
+      const unsigned long long* r = &h[i * 8];
+      if (!r[3]) continue;
+      const double steps = (double)((r[5] + 3) / 4) * (double)(ivf->dpad / 16);
+      s_loc += (double)(r[1] - r[0]);
+      s_tile += (double)(r[2] - r[1]);
+      s_comp += (double)(r[3] - r[2]);
+      s_steps += steps;
+      s_blocks += (double)r[5];
+      per_xcd[r[7] & 15]++;
+      per_step.push_back((double)(r[3] - r[2]) / steps);
+    }
+    std::sort(per_step.begin(), per_step.end());
+    const double tick = 0.01;  // us per tick of the 100 MHz wall clock
+    fprintf(stderr,
+            "[mfma stamps] launch %d: %zu items, %0.f blocks, span %.1f us | per item (wave 0): locate %.2f us, tile %.2f us, "
+            "compute %.2f us | per 16-dim step: mean %.3f us, p10 %.3f, p50 %.3f, p90 %.3f | items per XCD",
+            stamps_launch, n, s_blocks, (double)(t_max - t_min) * tick, s_loc / n * tick, s_tile / n * tick, s_comp / n * tick,
+            s_comp / s_steps * tick, per_step.empty() ? 0.0 : per_step[per_step.size() / 10] * tick,
+            per_step.empty() ? 0.0 : per_step[per_step.size() / 2] * tick,
+            per_step.empty() ? 0.0 : per_step[per_step.size() * 9 / 10] * tick);
+    for (int x = 0; x < 8; ++x) fprintf(stderr, " %zu", per_xcd[x]);
+    // when did the last item START, and how long were the items that finished last
+    unsigned long long last_start = 0;
+    for (size_t i = 0; i < kStampsCap; ++i)
+      if (h[i * 8 + 3]) last_start = std::max(last_start, h[i * 8]);
+    fprintf(stderr, " | last item drawn at %.1f us\n", (double)(last_start - t_min) * tick);
+    a.stamps = nullptr;
+  }
   if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[7], ctx->stream);
   if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[4], ctx->stream);
   S.pend_filter = true;

@@ -37,6 +37,7 @@ namespace fvdb {
 #ifndef FVDB_FAST_ADD_UNROLL
 #define FVDB_FAST_ADD_UNROLL 16  // LDS reads in flight ahead of the add chain (8: 1 % slower; 32: spills)
 #endif
+constexpr int kFastAddUnroll = FVDB_FAST_ADD_UNROLL;
 #ifndef FVDB_FAST_WAVES16
 #define FVDB_FAST_WAVES16 3      // waves per SIMD the 16-row form is compiled for (its LDS allows two workgroups per CU)
 #endif
@@ -98,7 +99,7 @@ __device__ __forceinline__ float score_fixed(const float* __restrict__ rows, uin
     float* cur = stage + (uint32_t)(c & 1) * tile_floats;
     if (c + 1 < NB) products(c + 1, stage + (uint32_t)((c + 1) & 1) * tile_floats);
     const float4* p = (const float4*)(cur + lrow * kFastStride);
-#pragma unroll FVDB_FAST_ADD_UNROLL
+#pragma unroll kFastAddUnroll
     for (int i = 0; i < 32; ++i) {
       const float4 v = p[i];
       acc = acc + v.x;

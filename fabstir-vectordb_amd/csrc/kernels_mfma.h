@@ -168,6 +168,9 @@ struct MfmaScanArgs {
   // (the draws of the other groups are no-ops): the segment comes from HBM once and from this CU's XCD L2 afterwards,
   // instead of once per group through whichever XCDs the groups' waves happen to run on
   uint32_t groups_in_item;
+  // dev aid (FVDB_MFMA_STAMPS): per work item 8 x u64 {drawn, located, tile in LDS, done, item, blocks, queries, XCD}
+  unsigned long long* stamps;
+  uint32_t stamps_cap;
 };
 
 // 16 dims of row `lane` of block `blk`: the raw 64 (f32) or 32 (fp16) bytes, requested early, and their
@@ -389,8 +392,14 @@ __global__ __launch_bounds__(256, FVDB_MFMA_WAVES) void scan_mfma_kernel(const M
     const uint32_t ngroups = (cnt + Q - 1) / Q;
     const uint32_t local = item - cload(a.item_off + L);
     const uint32_t seg = local / ngroups, g = local - seg * ngroups;
+#ifdef FVDB_EXP_HOT  // timing experiment only (wrong results): every segment reads the same 1.5 MB -> all rows L2-hot
+    const uint32_t b_begin_true = cload(a.list_off + L);
+    const uint32_t nblk = cload(a.list_off + L + 1) - b_begin_true;
+    const uint32_t b_begin = 0;
+#else
     const uint32_t b_begin = cload(a.list_off + L);
     const uint32_t nblk = cload(a.list_off + L + 1) - b_begin;
+#endif
     const uint32_t b0 = seg * a.segb;
     const uint32_t b1 = min(b0 + a.segb, nblk);
     if (MODE == 1 && b0 >= a.capA) continue;

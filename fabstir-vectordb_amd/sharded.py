@@ -135,6 +135,60 @@ class Comm:
             self.h = None
 
 
+def self_test(comm):
+    """One all-gather and one all-to-all of rank-stamped words through `comm`, checked on the host: the bring-up check
+    a launcher runs before trusting a fresh communicator with the data path.  Raises on a wrong word."""
+    ctx, W, r = comm.ctx, comm.world, comm.rank
+    n = 64  # u32 words per block
+    send_g = np.full(n, 0xA000 + r, np.uint32)
+    send_a = (0xB000 + 256 * r + np.repeat(np.arange(W, dtype=np.uint32), n)).astype(np.uint32)  # block p -> rank p
+    d_sg, d_sa = ctx.upload(send_g), ctx.upload(send_a)
+    d_rg, d_ra = ctx.alloc(4 * n * W), ctx.alloc(4 * n * W)
+    try:
+        comm.all_gather_dev(d_sg, d_rg, 4 * n)
+        comm.all_to_all_dev(d_sa, d_ra, 4 * n)
+        ctx.device_synchronize()
+        got_g = ctx.download(d_rg, (W, n), np.uint32)
+        got_a = ctx.download(d_ra, (W, n), np.uint32)
+    finally:
+        for p in (d_sg, d_sa, d_rg, d_ra):
+            ctx.free(p)
+    want_g = 0xA000 + np.arange(W, dtype=np.uint32)[:, None] + np.zeros((1, n), np.uint32)
+    want_a = 0xB000 + 256 * np.arange(W, dtype=np.uint32)[:, None] + r + np.zeros((1, n), np.uint32)
+    if not (np.array_equal(got_g, want_g) and np.array_equal(got_a, want_a)):
+        raise RuntimeError(f"rank {r}: communicator self-test moved wrong data")
+
+
+def bring_up(ctx, dist, torch, transport="rccl", timeout_s=180.0, log=print):
+    """The communicator a multi-rank launcher should use: RCCL, created and self-tested under a watchdog; when any rank
+    fails (or does not finish in `timeout_s`) EVERY rank switches to the hosted transport — same C data path, the two
+    exchanges carried by `dist` on host buffers — and says so loudly.  Returns (comm, transport actually in use)."""
+    if transport == "hosted":
+        return Comm.hosted(ctx, dist, torch), "hosted"
+    import threading
+    box = {}
+
+    def work():
+        try:
+            c = Comm.rccl(ctx, dist, torch)
+            self_test(c)
+            box["comm"] = c
+        except Exception as e:  # noqa: BLE001 — reported below, on every rank
+            box["err"] = repr(e)
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    ok = 1 if ("comm" in box and not t.is_alive()) else 0
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return box["comm"], "rccl"
+    why = box.get("err", "timed out" if t.is_alive() else "another rank failed")
+    log(f"RCCL bring-up FAILED on at least one rank (this rank: {why}); every rank continues on the HOSTED transport")
+    return Comm.hosted(ctx, dist, torch), "hosted (RCCL bring-up failed)"
+
+
 class ShardedHybrid:
     """HybridIndex across `comm.world` ranks (see the module docstring).  Bench / scale surface: bulk placement and
     batched search with several steps in flight; per-search auto-migration is not run in this mode (nothing ages

@@ -28,6 +28,7 @@ def ctx(fv):
 def test_rccl_communicator_of_one_rank(fv, ctx):
     sh = fv.sharded
     comm = sh.Comm.rccl(ctx)  # librccl is dlopen'ed here
+    sh.self_test(comm)
     assert (comm.world, comm.rank) == (1, 0)
     assert ctx.lib.fvdb_comm_world(comm.h) == 1 and ctx.lib.fvdb_comm_rank(comm.h) == 0
     a = np.arange(1000, dtype=np.uint32)
