@@ -584,7 +584,7 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   IvfScratch& S = *E.S;
   // tuning aids
   static const int M_env = env_u("FVDB_MFMA_M", 2), segb_env = env_u("FVDB_MFMA_SEGB", 0),
-                   segbA_env = env_u("FVDB_MFMA_SEGB_A", 1), capA_env = env_u("FVDB_MFMA_CAP_A", 8), wgs_env = env_u("FVDB_MFMA_WGS_PER_CU", 2);
+                   segbA_env = env_u("FVDB_MFMA_SEGB_A", 1), capA_env = env_u("FVDB_MFMA_CAP_A", 4), wgs_env = env_u("FVDB_MFMA_WGS_PER_CU", 2);
   static const int wg_m_env = env_u("FVDB_MFMA_WG_M", 4);
   int M = M_env >= 4 ? 4 : (M_env >= 2 ? 2 : 1);
   // the workgroup form of the filter (kernels_mfma_wg.h): fp16 rows, dpad a multiple of 128, 32 or 64 queries per group

@@ -208,6 +208,70 @@ __device__ __forceinline__ void operands_a16(const RowChunk16<ST>& r, h8v& a0, h
   }
 }
 
+// End of a block in the filter (MODE 0): v = |x|^2 - 2 acc for the lane's 16 rows x M queries, rows with v <= thr
+// survive.  The survivors of a block are appended with ONE atomic per (lane, query) — its count — and plain stores
+// behind it: an atomic per survivor made every survivor a round trip to L2 that the whole wave waited for, some
+// twenty per block, which cost more than streaming the block.
+// D layout: column = lane & 31 (query slot, and which 32-row half), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+struct BlockNorms {
+  float4 xn[4];     // |x|^2 of the lane's 16 rows
+  uint64_t vmask;   // live rows of the block
+};
+__device__ __forceinline__ void load_block_norms(const MfmaScanArgs& a, uint32_t blk, uint32_t rowbase, BlockNorms& o) {
+  o.vmask = cload(a.pool_valid + blk);
+  const float* np = a.pool_norms + (size_t)blk * 64 + rowbase;
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) o.xn[r4] = *(const float4*)(np + 8 * r4);
+}
+template <int M>
+__device__ __forceinline__ void emit_survivors(const MfmaScanArgs& a, const f32x16m (&acc)[M], const float (&thr)[M],
+                                               const bool (&hasq)[M], const uint32_t (&qidx)[M], const uint32_t (&rnk)[M],
+                                               uint32_t b, const BlockNorms& bn, uint32_t rowbase) {
+  const uint64_t vmask = bn.vmask;
+  float xv[16];
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) {
+    xv[4 * r4 + 0] = bn.xn[r4].x;
+    xv[4 * r4 + 1] = bn.xn[r4].y;
+    xv[4 * r4 + 2] = bn.xn[r4].z;
+    xv[4 * r4 + 3] = bn.xn[r4].w;
+  }
+  uint32_t live = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) live |= (uint32_t)((vmask >> (rowbase + 8 * (r >> 2) + (r & 3))) & 1ull) << r;
+  uint32_t flags[M], base[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    uint32_t f = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = __builtin_fmaf(-2.0f, acc[m][r], xv[r]);
+      f |= (uint32_t)(!(v > thr[m])) << r;  // NaN (non-finite operands) survives
+    }
+    flags[m] = hasq[m] ? (f & live) : 0u;
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m) base[m] = flags[m] ? atomicAdd(a.scnt + qidx[m], (uint32_t)__popc(flags[m])) : 0u;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    if (flags[m] == 0u) continue;
+    const size_t row0 = (size_t)qidx[m] * a.cmax;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if ((flags[m] >> r) & 1u) {
+        const uint32_t p = base[m] + (uint32_t)__popc(flags[m] & ((1u << r) - 1u));
+        if (p < a.cmax) {
+          u32x2 sv;
+          sv.x = rnk[m];
+          sv.y = b * 64 + rowbase + 8 * (r >> 2) + (r & 3);
+          a.surv[row0 + p] = sv;
+          a.sval[row0 + p] = __builtin_fmaf(-2.0f, acc[m][r], xv[r]);
+        }
+      }
+    }
+  }
+}
+
 // One work item: blocks [b0, b1) of a list against the ne (<= 16 M) queries of a group.
 template <int M, int ST, int MODE>
 __device__ __forceinline__ void mfma_item(const MfmaScanArgs& a, const uint32_t b_begin, const uint32_t b0,
@@ -248,32 +312,25 @@ __device__ __forceinline__ void mfma_item(const MfmaScanArgs& a, const uint32_t 
 
   // after the last 16-dim step of block b (list position), blk (pool block): threshold test / slot minima
   auto block_done = [&](uint32_t b, uint32_t blk) {
-    // D layout: column = lane & 31 (query slot, and which 32-row half), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    const uint64_t vmask = cload(a.pool_valid + blk);
-    const float* np = a.pool_norms + (size_t)blk * 64 + rowbase;
+    if (MODE == 0) {
+      BlockNorms bn;
+      load_block_norms(a, blk, rowbase, bn);
+      emit_survivors<M>(a, acc, thr, hasq, qidx, rnk, b, bn, rowbase);
+    } else {
+      // D layout: column = lane & 31 (query slot, and which 32-row half), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+      const uint64_t vmask = cload(a.pool_valid + blk);
+      const float* np = a.pool_norms + (size_t)blk * 64 + rowbase;
 #pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const float4 xn = *(const float4*)(np + 8 * r4);
-      const float xv[4] = {xn.x, xn.y, xn.z, xn.w};
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float4 xn = *(const float4*)(np + 8 * r4);
+        const float xv[4] = {xn.x, xn.y, xn.z, xn.w};
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const uint32_t row = rowbase + 8 * r4 + t;
-        const bool live = (vmask >> row) & 1ull;
+        for (int t = 0; t < 4; ++t) {
+          const uint32_t row = rowbase + 8 * r4 + t;
+          const bool live = (vmask >> row) & 1ull;
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-          const float v = __builtin_fmaf(-2.0f, acc[m][4 * r4 + t], xv[t]);
-          if (MODE == 0) {
-            if (hasq[m] && live && !(v > thr[m])) {  // NaN (non-finite operands) survives
-              const uint32_t p = atomicAdd(a.scnt + qidx[m], 1u);
-              if (p < a.cmax) {
-                u32x2 sv;
-                sv.x = rnk[m];
-                sv.y = b * 64 + row;
-                a.surv[(size_t)qidx[m] * a.cmax + p] = sv;
-                a.sval[(size_t)qidx[m] * a.cmax + p] = v;
-              }
-            }
-          } else {
+          for (int m = 0; m < M; ++m) {
+            const float v = __builtin_fmaf(-2.0f, acc[m][4 * r4 + t], xv[t]);
             if (live && v < best[m][4 * r4 + t]) best[m][4 * r4 + t] = v;
           }
         }

@@ -58,33 +58,11 @@ __device__ __forceinline__ void mfma_item_wg(const MfmaScanArgs& a, const unsign
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
 
-  auto block_done = [&](uint32_t b, uint32_t blk) {
-    const uint64_t vmask = cload(a.pool_valid + blk);
-    const float* np = a.pool_norms + (size_t)blk * 64 + rowbase;
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const float4 xn = *(const float4*)(np + 8 * r4);
-      const float xv[4] = {xn.x, xn.y, xn.z, xn.w};
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const uint32_t row = rowbase + 8 * r4 + t;
-        const bool live = (vmask >> row) & 1ull;
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-          const float v = __builtin_fmaf(-2.0f, acc[m][4 * r4 + t], xv[t]);
-          if (hasq[m] && live && !(v > thr[m])) {  // NaN (non-finite operands) survives
-            const uint32_t p = atomicAdd(a.scnt + qidx[m], 1u);
-            if (p < a.cmax) {
-              u32x2 sv;
-              sv.x = rnk[m];
-              sv.y = b * 64 + row;
-              a.surv[(size_t)qidx[m] * a.cmax + p] = sv;
-              a.sval[(size_t)qidx[m] * a.cmax + p] = v;
-            }
-          }
-        }
-      }
-    }
+  // |x|^2 and the live mask of the block being consumed are requested one ring ahead of its last step: vmcnt retires
+  // in order, so asking for them at the end of the block would first drain every row step in flight
+  BlockNorms bn;
+  auto block_done = [&](uint32_t b) {
+    emit_survivors<M>(a, acc, thr, hasq, qidx, rnk, b, bn, rowbase);
 #pragma unroll
     for (int m = 0; m < M; ++m)
 #pragma unroll
@@ -118,6 +96,7 @@ __device__ __forceinline__ void mfma_item_wg(const MfmaScanArgs& a, const unsign
   read_q(0, qf0[0], qf1[0]);
   uint32_t b = bw, cc = 0;  // step being consumed
   for (uint32_t s = 0; s < total; s += D) {
+    if (cc + D == n) load_block_norms(a, cload(a.list_blocks + b_begin + b), rowbase, bn);
 #pragma unroll
     for (int u = 0; u < D; ++u) {
       issue_row(ring[(u + D - 1) & (D - 1)]);
@@ -134,7 +113,7 @@ __device__ __forceinline__ void mfma_item_wg(const MfmaScanArgs& a, const unsign
     cc += D;
     if (cc == n) {
       cc = 0;
-      block_done(b, cload(a.list_blocks + b_begin + b));
+      block_done(b);
       b += 4;
     }
   }

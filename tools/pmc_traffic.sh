@@ -11,8 +11,10 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --outp
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d gpurun_out/pmc_busy -- python3 bench.py $ARGS > /dev/null 2> gpurun_out/pmc_busy.log
 python3 - <<PY
 import csv, glob, collections, json
-names = {"scan_mfma_kernel<2, 1, 0>": "list_scan", "scan_mfma_kernel<2, 1, 1>": "threshold_pass", "hnsw_search_fast_kernel": "graph_traversal",
-         "coarse_gemm_kernel": "coarse_gemm", "coarse_select_kernel": "coarse_select", "select_kernel<": "select"}
+names = {"scan_mfma_wg_kernel": "list_scan", "scan_mfma_kernel<2, 1, 0>": "list_scan_wave_form", "scan_mfma_kernel<2, 1, 1>": "threshold_pass",
+         "threshold_direct_kernel": "threshold", "hnsw_search_fast_kernel": "graph_traversal", "coarse_gemm_kernel": "coarse_gemm",
+         "coarse_select_kernel": "coarse_select", "select_kernel<": "select", "merge_topk_kernel": "merge", "plan_": "plan",
+         "prep_queries_kernel": "prep_queries", "hybrid_merge": "hybrid_merge"}
 out = {}
 for tag in ("fetch", "write", "mfma", "busy"):
     for f in glob.glob("gpurun_out/pmc_%s/*/*counter_collection.csv" % tag) + glob.glob("gpurun_out/pmc_%s/*counter_collection.csv" % tag):
@@ -23,7 +25,8 @@ for tag in ("fetch", "write", "mfma", "busy"):
             for pat, name in names.items():
                 if pat in k:
                     # bench-time launches only matter on average: the sweep and warmup launches are the same kernel
-                    out.setdefault(name, {})[ctr + ("_KB_avg" if ctr.endswith("_SIZE") else "_avg")] = sum(v) / len(v)
+                    v = sorted(v)
+                    out.setdefault(name, {})[ctr + ("_KB_avg" if ctr.endswith("_SIZE") else "_avg")] = v[len(v) // 2]  # median launch
                     out[name]["launches"] = len(v)
 try:
     b = json.loads(open("gpurun_out/pmc_bench.json").read().strip().splitlines()[-1])
