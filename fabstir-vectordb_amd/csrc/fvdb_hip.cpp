@@ -118,6 +118,10 @@ struct Pool {
   float* norms = nullptr;  // |x|^2 per row (matrix-core filter, kernels_mfma.h)
   bool mirror = false;     // f32 pools: keep an fp16 (round-to-nearest) copy of the rows for the matrix-core filter
   void* half = nullptr;    // [blocks][d8][64] 8-half chunks, same lane = row layout
+  // f32 pools with the mirror also keep the rows ROW-MAJOR ([blocks * 64][dpad] f32, bit copies): the select stage
+  // scores some twenty single rows per query, and in the blocked layout every 16 bytes of a row sit in a different
+  // cache line (12 KB fetched per 1.5 KB row)
+  float* rm = nullptr;
   size_t block_bytes() const { return (size_t)d4 * 4 * esize * 64; }
   PoolView view() const { return PoolView{data, ids, valid, d4}; }
   void release() {
@@ -125,6 +129,8 @@ struct Pool {
     norms = nullptr;
     if (half) (void)hipFree(half);
     half = nullptr;
+    if (rm) (void)hipFree(rm);
+    rm = nullptr;
     if (data) (void)hipFree(data);
     if (ids) (void)hipFree(ids);
     if (valid) (void)hipFree(valid);
@@ -145,6 +151,13 @@ struct Pool {
     // rows never written (the tail of each list's last block) must be finite: they share MFMA instructions with
     // live rows, and 0 x NaN would poison those
     HIPCHK(ctx, hipMemsetAsync(nd, 0, (size_t)ncap * block_bytes(), ctx->stream));
+    float* nr = nullptr;
+    if (mirror && esize == 4) {
+      HIPCHK(ctx, hipMalloc((void**)&nr, (size_t)ncap * block_bytes()));
+      HIPCHK(ctx, hipMemsetAsync(nr, 0, (size_t)ncap * block_bytes(), ctx->stream));
+      if (used_blocks && rm)
+        HIPCHK(ctx, hipMemcpyAsync(nr, rm, (size_t)used_blocks * block_bytes(), hipMemcpyDeviceToDevice, ctx->stream));
+    }
     void* nh = nullptr;
     if (mirror) {
       HIPCHK(ctx, hipMalloc(&nh, (size_t)ncap * block_bytes() / 2));
@@ -173,6 +186,8 @@ struct Pool {
     if (norms) (void)hipFree(norms);
     if (half) (void)hipFree(half);
     half = nh;
+    if (rm) (void)hipFree(rm);
+    rm = nr;
     norms = nn;
     data = nd;
     ids = ni;
@@ -795,6 +810,7 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   v.dpad = ivf->dpad;
   v.cmax = cmax;
   v.rows_f16 = x_rounded;
+  v.rows_rm = ivf->pool.rm;
   v.out_ids = out_ids;
   v.out_dist = out_dist;
   v.out_counts = out_counts;
@@ -1192,7 +1208,8 @@ static int install_centroids(fvdb_ivf* ivf, const float* d_rowmajor /* device [n
   const uint64_t threads = (uint64_t)nlist * ivf->d4;
   hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, ctx->stream, d_rowmajor, ivf->d,
                      ivf->d4, (uint64_t)nlist, ivf->s_slots.as<uint32_t>(), (const uint64_t*)nullptr,
-                     (float4*)ivf->cpool.data, ivf->cpool.ids, (unsigned long long*)ivf->cpool.valid, (void*)nullptr);
+                     (float4*)ivf->cpool.data, ivf->cpool.ids, (unsigned long long*)ivf->cpool.valid, (void*)nullptr,
+                     (float4*)nullptr);
   // matrix-core coarse stage: padded row-major table, |c|^2, max |c|^2
   const float* cpad = d_rowmajor;
   if (ivf->d != ivf->dpad) {
@@ -1392,7 +1409,8 @@ static int append_staged(fvdb_ivf* ivf, const uint64_t* ids, uint64_t n, const u
     const uint64_t threads = n * ivf->d4;
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, ctx->stream, ivf->s_in.as<float>(),
                        ivf->d, ivf->d4, n, ivf->s_slots.as<uint32_t>(), ids ? ivf->s_ids.as<uint64_t>() : nullptr,
-                       (float4*)ivf->pool.data, ivf->pool.ids, (unsigned long long*)ivf->pool.valid, ivf->pool.half);
+                       (float4*)ivf->pool.data, ivf->pool.ids, (unsigned long long*)ivf->pool.valid, ivf->pool.half,
+                       (float4*)ivf->pool.rm);
   }
   if (!ivf->d_xmax.p) {
     HIPCHK(ctx, ivf->d_xmax.ensure(4));

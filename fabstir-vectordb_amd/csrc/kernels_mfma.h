@@ -508,6 +508,22 @@ __device__ __forceinline__ float exact_row_dist(const void* __restrict__ pool_da
   return sqrtf(acc);
 }
 
+// The same fold over a row stored contiguously (the pool's row-major copy): same values, same order.
+__device__ __forceinline__ float exact_row_dist_rm(const float* __restrict__ x, uint32_t d4, const float* __restrict__ q) {
+  float acc = 0.0f;
+  const float4* xp = (const float4*)x;
+  for (uint32_t c = 0; c < d4; ++c) {
+    const float4 xv = xp[c];
+    const f32x4 qv = cload((const f32x4*)(q + 4 * c));
+    float t;
+    t = xv.x - qv.x; acc = acc + t * t;
+    t = xv.y - qv.y; acc = acc + t * t;
+    t = xv.z - qv.z; acc = acc + t * t;
+    t = xv.w - qv.w; acc = acc + t * t;
+  }
+  return sqrtf(acc);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Error bound and order-preserving float -> uint map shared by the threshold and select kernels.
 //   E_q >= | (v + |q|^2) - reference f32 sum | for every row x of the pool:
@@ -693,6 +709,7 @@ struct VerifyArgs {
   const uint32_t* scnt;         // [B]
   uint32_t B, k, ka, nprobe, d, dpad, cmax;
   int rows_f16;
+  const float* rows_rm;  // row-major f32 copy of the pool (f32 pools with the fp16 mirror), else null
   uint64_t* out_ids;
   float* out_dist;
   uint32_t* out_counts;
@@ -782,8 +799,10 @@ __global__ __launch_bounds__(256) void select_kernel(const VerifyArgs m) {
       const u32x2 sv = m.surv[(size_t)q * m.cmax + s_cand[w][lane]];
       const uint32_t L = m.probes[(size_t)q * np + sv.x];
       const uint32_t blk = m.lists.blocks[m.lists.off[L] + (sv.y >> 6)];
-      khi = __float_as_uint(
-          exact_row_dist<ST>(m.pool.data, m.pool.d4, blk, (int)(sv.y & 63), m.queries + (size_t)q * m.dpad));
+      const float* qrow = m.queries + (size_t)q * m.dpad;
+      khi = __float_as_uint(ST == 0 && m.rows_rm
+                                ? exact_row_dist_rm(m.rows_rm + ((size_t)blk * 64 + (sv.y & 63)) * m.dpad, m.pool.d4, qrow)
+                                : exact_row_dist<ST>(m.pool.data, m.pool.d4, blk, (int)(sv.y & 63), qrow));
       klo = s_base[w][sv.x] + sv.y;
     }
     wave_sort64(khi, klo, lane);

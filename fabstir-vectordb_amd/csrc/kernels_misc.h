@@ -10,7 +10,8 @@ namespace fvdb {
 __global__ void scatter_rows_kernel(const float* __restrict__ src, uint32_t d, uint32_t d4, uint64_t n,
                                     const uint32_t* __restrict__ dst_slot, const uint64_t* __restrict__ row_ids,
                                     float4* __restrict__ pool_data, uint64_t* __restrict__ pool_ids,
-                                    unsigned long long* __restrict__ pool_valid, void* __restrict__ pool_half) {
+                                    unsigned long long* __restrict__ pool_valid, void* __restrict__ pool_half,
+                                    float4* __restrict__ pool_rm) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t i = t / d4;
   const uint32_t c = (uint32_t)(t % d4);
@@ -24,6 +25,7 @@ __global__ void scatter_rows_kernel(const float* __restrict__ src, uint32_t d, u
   v.z = (4 * c + 2 < d) ? r[2] : 0.0f;
   v.w = (4 * c + 3 < d) ? r[3] : 0.0f;
   pool_data[((size_t)blk * d4 + c) * 64 + lane] = v;
+  if (pool_rm) pool_rm[((size_t)blk * 64 + lane) * d4 + c] = v;  // row-major copy (select stage)
   if (pool_half) {  // fp16 mirror (round to nearest even) in the fp16 pool layout: 8 halves per 16-byte chunk
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     const h4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
