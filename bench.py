@@ -507,7 +507,7 @@ def build_roofline(args, d, B, rows_out, world, stage, n_prof, stats, graph_ms_s
                 "card to itself)",
         "list_scan": {
             "bound": "hbm" if t_bytes >= t_flops else "mfma",
-            "kernel": ("fvdb::scan_mfma_kernel (IVF list scan: fp16 MFMA filter over every probed row)" if mfma_path
+            "kernel": ("fvdb::scan_mfma_wg_kernel<4> (IVF list scan: fp16 MFMA filter over every probed row, query groups in LDS)" if mfma_path
                        else "fvdb::scan_topk_kernel (IVF list scan, exact)"),
             "kernel_ms": round(scan_ms, 4),
             "physical_lower_bound_bytes": int(phys_bytes), "useful_flops": int(flops),
