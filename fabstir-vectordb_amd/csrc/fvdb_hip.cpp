@@ -605,7 +605,8 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   // the workgroup form of the filter (kernels_mfma_wg.h): fp16 rows, dpad a multiple of 128, 32 or 64 queries per group
   static const int wg_env = env_u("FVDB_MFMA_WG", 1), wg_segb_env = env_u("FVDB_MFMA_WG_SEGB", 16),
                    wg_wgs_env = env_u("FVDB_MFMA_WG_PER_CU", 2);
-  const int wgM = wg_m_env >= 4 ? 4 : 2;
+  int wgM = wg_m_env >= 4 ? 4 : 2;
+  if (mfma_wg_lds_bytes(ivf->dpad, 16u * wgM) > 64u * 1024u) wgM = 2;  // wide rows: the 32-query tile still fits
   const bool use_wg = wg_env && M == 2 && (ivf->f16 || ivf->pool.half != nullptr) && ivf->dpad % 128 == 0 &&
                       mfma_wg_lds_bytes(ivf->dpad, 16u * wgM) <= 64u * 1024u;
   if (use_wg) M = wgM;

@@ -74,7 +74,9 @@ def run_modes(gpu, cpu, q, k, nprobe):
                                                   (128, 64, 40000, 96, 58, 12),
                                                   (256, 100, 30000, 33, 5, 100), (16, 16, 5000, 40, 10, 3),
                                                   # every list probed by all 200 queries: query groups of 64, 64, 64 and 8
-                                                  (128, 16, 20000, 200, 10, 16), (384, 24, 30000, 113, 7, 24)])
+                                                  (128, 16, 20000, 200, 10, 16), (384, 24, 30000, 113, 7, 24),
+                                                  # wide rows: 32-query LDS tile (768), wave form (1024)
+                                                  (768, 32, 12000, 70, 10, 8), (1024, 16, 6000, 64, 5, 6)])
 def test_mfma_scan_matches_oracle(fv, ctx, d, nlist, n, B, k, nprobe):
     x = mixture(n, d, seed=100 + d)
     ids = np.arange(n, dtype=np.uint64) * 3 + 1
