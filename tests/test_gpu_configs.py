@@ -81,6 +81,15 @@ def test_c4_lists_sharded_over_8_emulated_gpus(fv, ctx):
     m_ids, m_ds, m_cnt = ctx.download(oi, (B, k), np.uint64), ctx.download(od, (B, k), np.float32), ctx.download(oc, B, np.uint32)
     w_ids, w_ds, w_cnt = whole.search(q, k, nprobe)
     assert np.array_equal(m_cnt, w_cnt) and np.array_equal(m_ids, w_ids) and np.array_equal(bits(m_ds), bits(w_ds))
+    # and against the oracle itself, not only the engine's own single index
+    cpu = orc.IVFIndex(n_clusters=nlist, n_probe=nprobe)
+    cpu.set_trained(cents)
+    cpu.batch_insert(ids, x)
+    c_ids, c_ds, c_cnt = cpu.batch_search(q, k, nprobe)
+    assert np.array_equal(m_cnt, c_cnt)
+    for i in range(B):
+        nn = int(c_cnt[i])
+        assert np.array_equal(m_ids[i, :nn], c_ids[i, :nn]) and np.array_equal(bits(m_ds[i, :nn]), bits(c_ds[i, :nn]))
     assert max(np.bincount(owner, weights=sizes)) - min(np.bincount(owner, weights=sizes)) <= sizes.max()
 
 
