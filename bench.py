@@ -157,6 +157,12 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     dist = torch = None
+    # stdout carries ONE JSON line and nothing else: libraries (gloo's "Rank 0 is connected to ..." lines, RCCL's version
+    # banner) write to file descriptor 1 whenever they like, so fd 1 is pointed at stderr for the whole run and the
+    # line goes to a private copy of the original descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     force_sharded = os.environ.get("FVDB_FORCE_SHARDED") == "1"  # exercise the multi-GPU code path on one rank
     if world > 1:
         import torch  # noqa: F811
@@ -211,24 +217,15 @@ def main():
     if world == 1 and not force_sharded:
         hyb.bulk_insert(ids, x, ts, now)
     else:
-        # RCCL prints a version banner on stdout when it initialises; stdout must carry ONE JSON line
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            if world > 1:
-                comm, transport_used = sh.bring_up(ctx_ivf, dist, torch, args.transport, log=log)
-            else:
-                comm, transport_used = sh.Comm.rccl(ctx_ivf, dist, torch), "rccl"
-                sh.self_test(comm)
-            sharded = sh.ShardedHybrid(hyb, comm)
-            sharded.bulk_insert(ids, x, ts, now)
-            if dist is not None:
-                dist.barrier()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+        if world > 1:
+            comm, transport_used = sh.bring_up(ctx_ivf, dist, torch, args.transport, log=log)
+        else:
+            comm, transport_used = sh.Comm.rccl(ctx_ivf, dist, torch), "rccl"
+            sh.self_test(comm)
+        sharded = sh.ShardedHybrid(hyb, comm)
+        sharded.bulk_insert(ids, x, ts, now)
+        if dist is not None:
+            dist.barrier()
     log(f"index build (HNSW bulk graph {hyb.recent_count()} nodes + IVF {hyb.historical_count()} rows): "
         f"{time.time() - t0:.1f}s")
 
@@ -465,7 +462,8 @@ def main():
         }
         if supplementary is not None:
             out["supplementary"] = supplementary
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

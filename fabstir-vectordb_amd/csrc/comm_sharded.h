@@ -143,7 +143,7 @@ struct fvdb_sharded {
   fvdb_ivf* ivf = nullptr;
   fvdb_comm* comm = nullptr;
   struct Slot {
-    DBuf probes, q_all, probes_all, keys, ids, dist, cnt, gk, gi;
+    DBuf probes, q_all, probes_all, keys, ids, dist, cnt, gk, gi, u_own, u_all, thr;
     size_t keys_zeroed = 0;
   } slot[fvdb_ivf::kSlots];
 };
@@ -305,9 +305,31 @@ int fvdb_ivf_search_sharded_begin(fvdb_sharded* s, fvdb_ctx* on, uint32_t slot, 
     q_scan = sl.q_all.as<float>();
     probes_scan = sl.probes_all.as<uint32_t>();
   }
-  // 2. the lists this rank owns, for all of them: partial top-k with global selection keys
-  rc = fvdb_ivf_search_probes_dev_slot(ivf, on, slot, q_scan, probes_scan, Bq, k, nprobe, sl.ids.as<uint64_t>(),
-                                       sl.dist.as<float>(), sl.cnt.as<uint32_t>(), sl.keys.as<uint64_t>());
+  // 2. the lists this rank owns, for all of them: partial top-k with global selection keys.  The filter's
+  //    threshold of a query comes from ONE list — by the logical index's sizes, the same choice on every rank — so only
+  //    the rank owning that list computes it; an all-gather of the ranks' arrays (+inf = not mine) and a minimum give
+  //    every rank every threshold.  Without this each rank would sample rows for all Bq queries: W times the work.
+  if (thr_share_ok(ivf, Bq, k, np)) {
+    HIPCHK(ctx, sl.u_own.ensure((size_t)Bq * 4));
+    HIPCHK(ctx, sl.thr.ensure((size_t)Bq * 4));
+    rc = shared_thresholds_slot(ivf, on, slot, q_scan, probes_scan, Bq, k, np, sl.u_own.as<float>());
+    if (rc) return rc;
+    const float* u_all = sl.u_own.as<float>();
+    if (W > 1) {
+      HIPCHK(ctx, sl.u_all.ensure((size_t)W * Bq * 4));
+      const Xfer x[1] = {{sl.u_own.p, sl.u_all.p, (size_t)Bq * 4}};
+      rc = comm_exchange(c, ctx, XCHG_ALL_GATHER, x, 1);
+      if (rc) return rc;
+      u_all = sl.u_all.as<float>();
+    }
+    rc = thr_combine_slot(ivf, on, slot, u_all, W, Bq, sl.thr.as<float>());
+    if (rc) return rc;
+    rc = search_probes_thr_slot(ivf, on, slot, q_scan, probes_scan, sl.thr.as<float>(), Bq, k, nprobe,
+                                sl.ids.as<uint64_t>(), sl.dist.as<float>(), sl.cnt.as<uint32_t>(), sl.keys.as<uint64_t>());
+  } else {
+    rc = fvdb_ivf_search_probes_dev_slot(ivf, on, slot, q_scan, probes_scan, Bq, k, nprobe, sl.ids.as<uint64_t>(),
+                                         sl.dist.as<float>(), sl.cnt.as<uint32_t>(), sl.keys.as<uint64_t>());
+  }
   if (rc) return rc;
   // 3. exchange 2: the partials of rank p's queries go to rank p
   const uint64_t* gk = sl.keys.as<uint64_t>();

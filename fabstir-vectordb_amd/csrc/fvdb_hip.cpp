@@ -283,6 +283,7 @@ namespace {
 struct Env {
   fvdb_ctx* ctx;
   IvfScratch* S;
+  const float* given_thr = nullptr;  // sharded search: filter thresholds already agreed between the ranks ([B], device)
 };
 inline IvfScratch& slot_scratch(fvdb_ivf* ivf, uint32_t slot) { return slot == 0 ? *ivf : ivf->spare[slot - 1]; }
 }  // namespace
@@ -685,7 +686,11 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   //    Direct form: one wave per query, one launch (kernels_mfma.h).  FVDB_MFMA_THRESHOLD_PASS=1 keeps the earlier
   //    form (first_probe + plan + matrix-core MODE 1 pass + threshold_kernel) for A/B runs.
   static const bool thr_pass = getenv("FVDB_MFMA_THRESHOLD_PASS") != nullptr;
-  if (!thr_pass) {
+  if (E.given_thr) {
+    // sharded search: the thresholds were computed once per query by the rank owning the list and combined across the
+    // ranks before this call (ivf_shared_thresholds + the exchange in comm_sharded.h)
+    a.thr = E.given_thr;
+  } else if (!thr_pass) {
     ThresholdArgs t{};
     t.rows = a.pool_data;
     t.pool_valid = a.pool_valid;
@@ -799,7 +804,8 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   v.queries = qpad;
   v.qn = S.s_qn2.as<float>();
   v.xmax_bits = ivf->d_xmax.as<uint32_t>();
-  v.thr = S.s_thr.as<float>();
+  v.thr = E.given_thr ? E.given_thr : S.s_thr.as<float>();
+  v.remote_thr = E.given_thr ? 1 : 0;
   v.surv = (const u32x2*)S.s_surv.p;
   v.sval = S.s_sdist.as<float>();
   v.scnt = S.s_scnt.as<uint32_t>();
@@ -944,6 +950,96 @@ uint32_t sub_batch(fvdb_ivf* ivf, uint32_t B, uint32_t k, uint32_t np) {
   fit = std::max<uint64_t>(fit, 1);
   fit = std::min<uint64_t>(fit, 16384);
   return (uint32_t)std::min<uint64_t>(fit, B);
+}
+
+// ---- sharded search: filter thresholds computed once per query across the ranks (comm_sharded.h) ----
+// Whether a sharded step of B scanned queries uses the shared thresholds.  Every rank must answer alike (the answer
+// decides whether a collective is issued), so only quantities that are the same on every rank enter: shapes, and the
+// LOGICAL index's longest list.
+bool thr_share_ok(fvdb_ivf* ivf, uint32_t B, uint32_t k, uint32_t np) {
+  static const bool env_exact = getenv("FVDB_SCAN_EXACT") != nullptr, env_off = getenv("FVDB_NO_SHARED_THR") != nullptr;
+  if (env_exact || env_off || ivf->scan_mode != 0) return false;
+  if (!(ivf->dpad % 16 == 0 && k + kMfmaSlack <= 32 && np <= 256 && B >= 32 && B <= 16384)) return false;
+  uint32_t gmax = 0;
+  if (ivf->glob_set) {
+    for (uint32_t b : ivf->glob_blocks_host) gmax = std::max(gmax, b);
+  } else {
+    gmax = ivf->max_list_blocks;
+  }
+  // one sub-batch on every rank (sub_batch() with the logical index's longest list: local lists are no longer)
+  const uint32_t segb = gmax >= 4096 ? 16 : ((uint64_t)B * np >= 4096 ? 4 : ((uint64_t)B * np >= 512 ? 2 : 1));
+  const uint64_t per_q = (uint64_t)np * std::max<uint32_t>(1, cdiv(gmax, segb)) * k * 8;
+  return (1ull << 30) / std::max<uint64_t>(per_q, 1) >= B;
+}
+
+// U_q (kernels_mfma.h, ThresholdArgs::glob_blocks) for the B queries of a sharded step, +inf where this rank does
+// not own the list the threshold comes from.  Leaves the slot's fp16 queries and |q|^2 in place for thr_combine.
+int ivf_shared_thresholds(fvdb_ivf* ivf, const Env& E, const float* q_dev, const uint32_t* probes, uint32_t B, uint32_t k,
+                          uint32_t np, float* u_out) {
+  fvdb_ctx* ctx = E.ctx;
+  IvfScratch& S = *E.S;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = upload_table(ivf);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> enq(S.enq);
+  HIPCHK(ctx, S.s_qn2.ensure((size_t)B * 4));
+  if (!ivf->pool.norms || !ivf->d_xmax.p) {  // no rows on this rank yet: it owns nothing
+    HIPCHK(ctx, hipMemsetAsync(S.s_qn2.p, 0, (size_t)B * 4, ctx->stream));
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, u_out, B, __builtin_huge_valf());
+    HIPCHK(ctx, hipGetLastError());
+    return FVDB_OK;
+  }
+  const float* qpad = nullptr;
+  rc = padded_queries(ivf, E, q_dev, B, &qpad);
+  if (rc) return rc;
+  HIPCHK(ctx, S.s_qh.ensure((size_t)(B + 1) * ivf->dpad * 2));
+  HIPCHK(ctx, S.s_cnt.ensure((size_t)ivf->nlist * 4));
+  HIPCHK(ctx, S.s_scnt.ensure((size_t)(B + 2) * 4));
+  HIPCHK(ctx, S.s_mslots.ensure((size_t)B * 64 * 4));
+  hipLaunchKernelGGL(prep_queries_kernel, dim3(cdiv(B + 1, 4)), dim3(256), 0, ctx->stream, qpad, B, ivf->dpad,
+                     (_Float16*)S.s_qh.p, S.s_qn2.as<float>(), S.s_cnt.as<uint32_t>(), ivf->nlist,
+                     S.s_scnt.as<uint32_t>(), S.s_mslots.as<uint32_t>());
+  static const int capA_env = env_u("FVDB_MFMA_CAP_A", 4);
+  const bool half_rows = ivf->f16 || ivf->pool.half != nullptr;
+  ThresholdArgs t{};
+  t.rows = ivf->pool.half ? ivf->pool.half : ivf->pool.data;
+  t.pool_valid = ivf->pool.valid;
+  t.pool_norms = ivf->pool.norms;
+  t.d4 = ivf->d4;
+  t.lists = ListTable{ivf->t_off.as<uint32_t>(), ivf->t_blocks.as<uint32_t>(), ivf->nlist};
+  t.list_len = ivf->t_len.as<uint32_t>();
+  t.probes = probes;
+  t.qh = (const _Float16*)S.s_qh.p;
+  t.queries = qpad;
+  t.qn = S.s_qn2.as<float>();
+  t.xmax_bits = ivf->d_xmax.as<uint32_t>();
+  t.B = B;
+  t.np = np;
+  t.ka = k + kMfmaSlack;
+  t.dpad = ivf->dpad;
+  t.capA = (uint32_t)std::max(1, capA_env);
+  t.min_rows = 256u;
+  t.rows_f16 = ivf->f16 ? 0 : (ivf->pool.half ? 1 : 2);
+  t.thr = u_out;
+  t.glob_blocks = ivf->t_glob.as<uint32_t>();
+  if (half_rows) hipLaunchKernelGGL((threshold_direct_kernel<true>), dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, t);
+  else hipLaunchKernelGGL((threshold_direct_kernel<false>), dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, t);
+  HIPCHK(ctx, hipGetLastError());
+  return FVDB_OK;
+}
+
+// thr = min over the ranks' U arrays + this rank's own error bound
+int ivf_thr_combine(fvdb_ivf* ivf, const Env& E, const float* u_all, uint32_t W, uint32_t B, float* thr_out) {
+  fvdb_ctx* ctx = E.ctx;
+  IvfScratch& S = *E.S;
+  if (!ivf->d_xmax.p) {
+    HIPCHK(ctx, ivf->d_xmax.ensure(4));
+    HIPCHK(ctx, hipMemsetAsync(ivf->d_xmax.p, 0, 4, ctx->stream));
+  }
+  hipLaunchKernelGGL(thr_combine_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, u_all, W, B, S.s_qn2.as<float>(),
+                     ivf->d_xmax.as<uint32_t>(), (float)ivf->dpad, ivf->f16 ? 0 : (ivf->pool.half ? 1 : 2), thr_out);
+  HIPCHK(ctx, hipGetLastError());
+  return FVDB_OK;
 }
 
 int check_finite(fvdb_ctx* ctx, const float* x, uint64_t n) {
@@ -1576,6 +1672,32 @@ int fvdb_ivf_search_probes_dev_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, 
   Env E{};
   int rc = slot_env(ivf, on, slot, &E);
   if (rc) return rc;
+  return slot_done(ivf, E, search_common(ivf, E, q_dev, B, k, nprobe, false, out_ids_dev, out_dist_dev, out_counts_dev,
+                                         out_keys_dev, probes_dev));
+}
+
+// the sharded step's variants (comm_sharded.h): thresholds shared between the ranks
+static int shared_thresholds_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev, const uint32_t* probes_dev,
+                                  uint32_t B, uint32_t k, uint32_t np, float* u_out) {
+  Env E{};
+  int rc = slot_env(ivf, on, slot, &E);
+  if (rc) return rc;
+  return slot_done(ivf, E, ivf_shared_thresholds(ivf, E, q_dev, probes_dev, B, k, np, u_out));
+}
+static int thr_combine_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* u_all, uint32_t W, uint32_t B,
+                            float* thr_out) {
+  Env E{};
+  int rc = slot_env(ivf, on, slot, &E);
+  if (rc) return rc;
+  return slot_done(ivf, E, ivf_thr_combine(ivf, E, u_all, W, B, thr_out));
+}
+static int search_probes_thr_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev, const uint32_t* probes_dev,
+                                  const float* thr_dev, uint32_t B, uint32_t k, uint32_t nprobe, uint64_t* out_ids_dev,
+                                  float* out_dist_dev, uint32_t* out_counts_dev, uint64_t* out_keys_dev) {
+  Env E{};
+  int rc = slot_env(ivf, on, slot, &E);
+  if (rc) return rc;
+  E.given_thr = thr_dev;
   return slot_done(ivf, E, search_common(ivf, E, q_dev, B, k, nprobe, false, out_ids_dev, out_dist_dev, out_counts_dev,
                                          out_keys_dev, probes_dev));
 }

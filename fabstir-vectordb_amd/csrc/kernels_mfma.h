@@ -597,6 +597,12 @@ struct ThresholdArgs {
   uint32_t B, np, ka, dpad, capA, min_rows;
   int rows_f16;               // x_rounded of mfma_error_bound
   float* thr;                 // [B]
+  // Sharded search: non-null = [nlist] blocks per list of the LOGICAL index.  The list is then chosen by the global
+  // sizes — the same choice on every rank — and only the rank that owns it finds rows there; the others write +inf and
+  // the ranks' arrays are combined with a minimum (comm_sharded.h), so each threshold is computed once per step.
+  // What is written then is U_q = a_q + E_owner: "k+6 rows of the logical index have reference sums <= U_q + |q|^2";
+  // every rank adds the error bound of ITS rows (thr_combine_kernel) — the bound depends on the rank's largest |x|.
+  const uint32_t* glob_blocks;
 };
 
 template <bool HALF>
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(256) void threshold_direct_kernel(const ThresholdAr
     uint32_t L = kInf32, len = 0;
     if (r < a.np) {
       L = a.probes[(size_t)q * a.np + r];
-      len = L != kInf32 ? a.list_len[L] : 0u;
+      len = L != kInf32 ? (a.glob_blocks ? a.glob_blocks[L] * 64u : a.list_len[L]) : 0u;
     }
     const uint64_t big = __ballot(len >= a.min_rows);
     if (big) {
@@ -685,11 +691,26 @@ __global__ __launch_bounds__(256) void threshold_direct_kernel(const ThresholdAr
       const float E = mfma_error_bound(__uint_as_float(*a.xmax_bits), a.qn[q], (float)a.dpad, a.rows_f16);
       if (kth != kInf32 && kth != 0u && E < inf) {
         const float av = funmap_u32(kth);
-        out = av + 2.0f * E + 1e-6f * fabsf(av);
+        out = av + (a.glob_blocks ? 1.0f : 2.0f) * E + 1e-6f * fabsf(av);
       }
     }
   }
   if (lane == 0) a.thr[q] = out;
+}
+
+// thr[i] = min over ranks of U[w][i] (+inf = "rank w does not own the list") + this rank's error bound for query i:
+// a row dropped here has v > U + E_here, hence a reference sum > U + |q|^2, beyond k+6 rows of the logical index.
+__global__ void thr_combine_kernel(const float* __restrict__ u_all, uint32_t W, uint32_t n, const float* __restrict__ qn,
+                                   const uint32_t* __restrict__ xmax_bits, float d, int rows_f16, float* __restrict__ thr) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float m = __builtin_huge_valf();
+  for (uint32_t w = 0; w < W; ++w) m = fminf(m, u_all[(size_t)w * n + i]);
+  thr[i] = m + mfma_error_bound(__uint_as_float(*xmax_bits), qn[i], d, rows_f16);
+}
+__global__ void fill_f32_kernel(float* __restrict__ p, uint32_t n, float v) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -710,6 +731,9 @@ struct VerifyArgs {
   uint32_t B, k, ka, nprobe, d, dpad, cmax;
   int rows_f16;
   const float* rows_rm;  // row-major f32 copy of the pool (f32 pools with the fp16 mirror), else null
+  // 1: thr[] bounds the (k+6)-th best row of the LOGICAL index and may come from another rank's rows, so fewer than
+  // k+6 survivors here is normal: every one of them is scored, and rows filtered out cannot be in the global answer
+  int remote_thr;
   uint64_t* out_ids;
   float* out_dist;
   uint32_t* out_counts;
@@ -814,7 +838,8 @@ __global__ __launch_bounds__(256) void select_kernel(const VerifyArgs m) {
       const uint32_t dk = rlane(khi, min(m.k, 64u) - 1);
       proven = dk != kInf32 && S > 0.0f && __uint_as_float(dk) < sqrtf(S);
     } else {
-      proven = m.thr[q] == inf;  // a finite filter threshold with < ka survivors cannot happen; be safe
+      // a finite threshold from this device's own rows leaves >= ka survivors; fewer means something is off
+      proven = m.remote_thr || m.thr[q] == inf;
     }
   }
   if (!proven) {  // hand the query to the exact rescan (fallback_scan_kernel + merge over the fail list)
