@@ -645,12 +645,13 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   hipLaunchKernelGGL(prep_queries_kernel, dim3(cdiv(B + 1, 4)), dim3(256), 0, ctx->stream, qpad, B, ivf->dpad,
                      (_Float16*)S.s_qh.p, S.s_qn2.as<float>(), S.s_cnt.as<uint32_t>(), nlist,
                      S.s_scnt.as<uint32_t>(), S.s_mslots.as<uint32_t>());
-  auto plan = [&](const uint32_t* pr, uint32_t n, uint32_t npp, uint32_t sb, unsigned long long* stats) {
+  auto plan = [&](const uint32_t* pr, uint32_t n, uint32_t npp, uint32_t sb, unsigned long long* stats,
+                  uint32_t lsplit = 0xFFFFFFFFu, uint32_t sb_tail = 0) {
     // cnt[] is zero on entry: cleared by prep_queries_kernel for the first plan, by plan_scan_kernel for the second
     hipLaunchKernelGGL(plan_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, pr, n, S.s_cnt.as<uint32_t>());
     hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, S.s_cnt.as<uint32_t>(), lists.off,
                        ivf->t_len.as<uint32_t>(), nlist, sb, Q, S.s_eoff.as<uint32_t>(), S.s_ioff.as<uint32_t>(),
-                       S.s_fill.as<uint32_t>(), scal + 2, scal + 3, stats, S.s_cnt.as<uint32_t>());
+                       S.s_fill.as<uint32_t>(), scal + 2, scal + 3, stats, S.s_cnt.as<uint32_t>(), lsplit, sb_tail);
     hipLaunchKernelGGL(plan_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, pr, n, npp,
                        S.s_eoff.as<uint32_t>(), S.s_fill.as<uint32_t>(), S.s_entries.as<uint2>());
   };
@@ -725,7 +726,15 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   }
 
   // B. filter over all probed lists
-  plan(probes, B * np, np, segb, (unsigned long long*)(scal + 4));
+  // workgroup form: the last quarter of the lists in small segments (see MfmaScanArgs::lsplit)
+  static const int wg_tail_pct = env_u("FVDB_MFMA_WG_TAIL_PCT", 25), wg_tail_segb = env_u("FVDB_MFMA_WG_SEGB_TAIL", 4);
+  a.lsplit = 0xFFFFFFFFu;
+  a.segb_tail = segb;
+  if (use_wg && wg_tail_pct > 0 && wg_tail_segb > 0 && (uint32_t)wg_tail_segb < segb) {
+    a.lsplit = (uint32_t)((uint64_t)nlist * (uint32_t)(100 - std::min(wg_tail_pct, 100)) / 100);
+    a.segb_tail = (uint32_t)wg_tail_segb;
+  }
+  plan(probes, B * np, np, segb, (unsigned long long*)(scal + 4), a.lsplit, a.segb_tail);
   a.segb = segb;
   if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[6], ctx->stream);
   static const int stamps_env = env_u("FVDB_MFMA_STAMPS", 0);  // dev aid: per-item timeline of the workgroup filter

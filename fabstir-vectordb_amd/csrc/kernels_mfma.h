@@ -171,6 +171,9 @@ struct MfmaScanArgs {
   // dev aid (FVDB_MFMA_STAMPS): per work item 8 x u64 {drawn, located, tile in LDS, done, item, blocks, queries, XCD}
   unsigned long long* stamps;
   uint32_t stamps_cap;
+  // workgroup form: lists >= lsplit are cut into segments of segb_tail blocks instead of segb — the queue's last
+  // items are small, so the workgroups finish together
+  uint32_t lsplit, segb_tail;
 };
 
 // 16 dims of row `lane` of block `blk`: the raw 64 (f32) or 32 (fp16) bytes, requested early, and their

@@ -151,8 +151,9 @@ __global__ __launch_bounds__(256, FVDB_MFMA_WG_WAVES) void scan_mfma_wg_kernel(c
     const uint32_t seg = local / ngroups, g = local - seg * ngroups;
     const uint32_t b_begin = cload(a.list_off + L);
     const uint32_t nblk = cload(a.list_off + L + 1) - b_begin;
-    const uint32_t b0 = seg * a.segb;
-    const uint32_t b1 = min(b0 + a.segb, nblk);
+    const uint32_t sb = L >= a.lsplit ? a.segb_tail : a.segb;
+    const uint32_t b0 = seg * sb;
+    const uint32_t b1 = min(b0 + sb, nblk);
     const uint32_t e0 = e_begin + g * Q;
     const uint32_t ne = min(Q, cnt - g * Q);
     // the group's queries -> LDS tile (row qi at qi * qstride), 16 bytes per thread per pass, 4 passes in flight

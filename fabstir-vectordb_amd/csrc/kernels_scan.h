@@ -466,7 +466,9 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ item_off, uint32_t* __restrict__ fill,
                                                          uint32_t* __restrict__ n_items, uint32_t* __restrict__ head,
                                                          unsigned long long* __restrict__ stats,
-                                                         uint32_t* __restrict__ rezero_cnt = nullptr) {
+                                                         uint32_t* __restrict__ rezero_cnt = nullptr,
+                                                         uint32_t lsplit = 0xFFFFFFFFu, uint32_t segb_tail = 0) {
+  // lists >= lsplit are cut into segments of segb_tail blocks (the last items of the work queue are small ones)
   __shared__ uint32_t s_e[1024], s_i[1024];
   __shared__ uint32_t carry_e, carry_i;
   __shared__ unsigned long long s_rows, s_touch;
@@ -483,7 +485,8 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const uint32_t* __restr
       c = cnt[L];
       if (rezero_cnt) rezero_cnt[L] = 0;  // consumed: ready for the next plan of the same batch
       const uint32_t nblk = list_off[L + 1] - list_off[L];
-      const uint32_t nseg = (nblk + segb - 1) / segb;
+      const uint32_t sb = L >= lsplit ? segb_tail : segb;
+      const uint32_t nseg = (nblk + sb - 1) / sb;
       it = (c == 0 || nblk == 0) ? 0u : nseg * ((c + Q - 1) / Q);
       fill[L] = 0;
       if (c) {
