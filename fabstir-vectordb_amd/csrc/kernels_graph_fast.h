@@ -49,7 +49,12 @@ __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
 }
 
 // LDS per wave: pending [64 u32] | scalars [16 u32] | two product tiles [R][kFastStride] floats
-__host__ __device__ inline size_t graph_fast_lds_bytes(uint32_t R) { return (64 + 16) * 4 + 2 * (size_t)R * kFastStride * 4; }
+#ifndef FVDB_FAST_TILES
+#define FVDB_FAST_TILES 2  // product tiles per wave: 2 = the products of block c + 1 are written during the add chain of block c
+#endif
+__host__ __device__ inline size_t graph_fast_lds_bytes(uint32_t R) {
+  return (64 + 16) * 4 + FVDB_FAST_TILES * (size_t)R * kFastStride * 4;
+}
 
 // Distances of the wave's query to `cnt` rows (1 <= cnt <= RC; lane r of `pn` holds the r-th row's node): returns, in
 // lane r < cnt, sqrt of the reference's sum.  q2[c] = dims (128c + 2*lane, +1) of the query, held in registers for the
@@ -96,8 +101,8 @@ __device__ __forceinline__ float score_fixed(const float* __restrict__ rows, uin
   float acc = 0.0f;
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
-    float* cur = stage + (uint32_t)(c & 1) * tile_floats;
-    if (c + 1 < NB) products(c + 1, stage + (uint32_t)((c + 1) & 1) * tile_floats);
+    float* cur = FVDB_FAST_TILES == 2 ? stage + (uint32_t)(c & 1) * tile_floats : stage;
+    if (FVDB_FAST_TILES == 2 && c + 1 < NB) products(c + 1, stage + (uint32_t)((c + 1) & 1) * tile_floats);
     const float4* p = (const float4*)(cur + lrow * kFastStride);
 #pragma unroll kFastAddUnroll
     for (int i = 0; i < 32; ++i) {
@@ -109,6 +114,11 @@ __device__ __forceinline__ float score_fixed(const float* __restrict__ rows, uin
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();  // tile c is rewritten by block c + 2, tile c + 1 is complete
+    if (FVDB_FAST_TILES == 1 && c + 1 < NB) {  // one tile: the next block's products only now
+      products(c + 1, stage);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
   }
   STAMP(tc2);
   STAMP_ADD(11, tc1, tc2);
