@@ -248,7 +248,9 @@ void fvdb_sharded_destroy(fvdb_sharded* s) {
   (void)hipSetDevice(s->ivf->ctx->device);
   (void)hipDeviceSynchronize();
   for (auto& sl : s->slot)
-    for (DBuf* b : {&sl.probes, &sl.q_all, &sl.probes_all, &sl.keys, &sl.ids, &sl.dist, &sl.cnt, &sl.gk, &sl.gi}) b->release();
+    for (DBuf* b : {&sl.probes, &sl.q_all, &sl.probes_all, &sl.keys, &sl.ids, &sl.dist, &sl.cnt, &sl.gk, &sl.gi, &sl.u_own, &sl.u_all,
+                    &sl.thr})
+      b->release();
   delete s;
 }
 
