@@ -96,14 +96,15 @@ class Comm:
     @classmethod
     def rccl(cls, ctx, dist=None, torch=None, world=1, rank=0):
         lib = ctx.lib
-        buf = np.zeros(128, np.uint8)
+        buf = np.zeros(129, np.uint8)  # 128 bytes of id + 1 status byte (1 = rank 0 could not draw an id)
         if dist is not None and dist.is_initialized():
             world, rank = dist.get_world_size(), dist.get_rank()
         if rank == 0:
             rc = lib.fvdb_comm_unique_id(buf.ctypes.data_as(C.c_void_p))
             if rc:
-                raise RuntimeError(f"fvdb_comm_unique_id failed with status {rc} (librccl missing?)")
+                buf[128] = 1
         if world > 1:
+            # always broadcast, also after a failure on rank 0: every rank must issue the same sequence of `dist` calls
             t = torch.from_numpy(buf)
             if dist.get_backend() == "nccl":
                 t = t.cuda()
@@ -111,6 +112,8 @@ class Comm:
                 buf = t.cpu().numpy()
             else:
                 dist.broadcast(t, 0)
+        if buf[128]:
+            raise RuntimeError("fvdb_comm_unique_id failed on rank 0 (librccl missing?)")
         h = C.c_void_p()
         ctx.check(lib.fvdb_comm_create(ctx.h, buf.ctypes.data_as(C.c_void_p), world, rank, C.byref(h)))
         return cls(ctx, h, world, rank)
