@@ -3,6 +3,7 @@ torch.distributed.run; all ranks share the box's one GPU, the collectives of the
 the hosted transport).  Every rank runs the product — ShardedHybrid over fvdb_ivf_search_sharded_begin/_end — in WEAK
 and STRONG mode, several steps in flight, and compares ITS OWN results bit for bit with the CPU oracle's search of the
 unsharded index.  Writes `rank<r>.json` into the directory given as argv[1]."""
+import ctypes as C
 import json
 import os
 import sys
@@ -28,7 +29,8 @@ def main():
     report = {"rank": rank, "world": world, "checks": []}
 
     DAY = 86400.0
-    n, d, nlist, k, nprobe, ef, B = 6000, 32, 24, 10, 6, 40, 37  # B not a multiple of world: ragged last slice
+    # B not a multiple of world: ragged last slice; lists of ~700 rows: the filter thresholds come from well-filled lists
+    n, d, nlist, k, nprobe, ef, B = 24000, 32, 24, 10, 6, 40, 37
     x = mixture(n, d, n_comp=16, sigma=1.0, seed=170)
     ids = np.arange(n, dtype=np.uint64) * 3 + 11
     cents = x[:nlist].copy()
@@ -98,6 +100,12 @@ def main():
     res = S.search_dev(gdev, 1, k, ef, nprobe, sh.STRONG)
     report["checks"].append(["strong_tiny", bool(res.counts.shape[0] == (1 if rank == 0 else 0) and
                                                  (rank != 0 or same(res, glob[:1])))])
+    # how often the matrix-core filter had to hand a query to the exact rescan on this rank (thresholds shared
+    # between the ranks must not make that the normal case)
+    fb = C.c_uint64(0)
+    ctx.lib.fvdb_ivf_scan_fallbacks(hyb.ivf()._dev(), C.byref(fb))
+    report["scan_fallbacks"] = int(fb.value)
+    report["queries_scanned"] = int(world * B * 4 + B * 2)  # weak: 4 steps of world*B; strong: B and 1
     report["ok"] = all(c[1] for c in report["checks"])
     json.dump(report, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
     dist.barrier()
