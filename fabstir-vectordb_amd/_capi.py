@@ -115,6 +115,7 @@ SIGNATURES = {
     "fvdb_comm_unique_id": (i32, [vp]),
     "fvdb_comm_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
     "fvdb_comm_create_hosted": (i32, [vp, i32, i32, vp, vp, C.POINTER(vp)]),
+    "fvdb_comm_create_loopback": (i32, [vp, i32, i32, C.POINTER(vp)]),
     "fvdb_comm_destroy": (None, [vp]),
     "fvdb_comm_rank": (i32, [vp]),
     "fvdb_comm_world": (i32, [vp]),

@@ -79,6 +79,7 @@ struct fvdb_comm {
   ncclComm_t nccl = nullptr;        // RCCL transport
   fvdb_exchange_fn fn = nullptr;    // hosted transport (tests / rehearsal): the caller moves host buffers
   void* user = nullptr;
+  bool loopback = false;            // capacity planning: exchanges are device copies of this rank's own blocks
   std::mutex mu;                    // one collective at a time per communicator, same order on every rank
   hipEvent_t last = nullptr;        // end of the previous collective of this communicator, on whichever stream it ran
   bool have_last = false;
@@ -122,6 +123,14 @@ int comm_exchange(fvdb_comm* c, fvdb_ctx* on, int op, const Xfer* x, int n) {
     RCCLCHK(on, g_rccl.GroupEnd());
     HIPCHK(on, hipEventRecord(c->last, on->stream));
     c->have_last = true;
+    return FVDB_OK;
+  }
+  if (c->loopback) {
+    for (int i = 0; i < n; ++i)
+      for (size_t p = 0; p < W; ++p) {
+        const char* src = (const char*)x[i].send + (op == XCHG_ALL_GATHER ? 0 : (size_t)c->rank * x[i].bytes);
+        HIPCHK(on, hipMemcpyAsync((char*)x[i].recv + p * x[i].bytes, src, x[i].bytes, hipMemcpyDeviceToDevice, on->stream));
+      }
     return FVDB_OK;
   }
   for (int i = 0; i < n; ++i) {
@@ -198,6 +207,20 @@ int fvdb_comm_create_hosted(fvdb_ctx* ctx, int world, int rank, fvdb_exchange_fn
   c->rank = rank;
   c->fn = fn;
   c->user = user;
+  *out = c;
+  return FVDB_OK;
+}
+
+int fvdb_comm_create_loopback(fvdb_ctx* ctx, int world, int rank, fvdb_comm** out) {
+  if (!ctx || !out) return FVDB_E_INVALID;
+  *out = nullptr;
+  if (world < 1 || rank < 0 || rank >= world) FAIL(ctx, FVDB_E_INVALID, "bad communicator shape");
+  fvdb_comm* c = new (std::nothrow) fvdb_comm();
+  if (!c) return FVDB_E_OOM;
+  c->ctx = ctx;
+  c->world = world;
+  c->rank = rank;
+  c->loopback = true;
   *out = c;
   return FVDB_OK;
 }
@@ -324,7 +347,7 @@ int fvdb_ivf_search_sharded_begin(fvdb_sharded* s, fvdb_ctx* on, uint32_t slot, 
       if (rc) return rc;
       u_all = sl.u_all.as<float>();
     }
-    rc = thr_combine_slot(ivf, on, slot, u_all, W, Bq, sl.thr.as<float>());
+    rc = thr_combine_slot(ivf, on, slot, u_all, W, Bq, sl.thr.as<float>(), c->loopback);
     if (rc) return rc;
     rc = search_probes_thr_slot(ivf, on, slot, q_scan, probes_scan, sl.thr.as<float>(), Bq, k, nprobe,
                                 sl.ids.as<uint64_t>(), sl.dist.as<float>(), sl.cnt.as<uint32_t>(), sl.keys.as<uint64_t>());

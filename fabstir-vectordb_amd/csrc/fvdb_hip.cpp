@@ -539,13 +539,13 @@ int run_fine_exact(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, u
   const uint32_t n = B * np;
   HIPCHK(ctx, hipMemsetAsync(S.s_cnt.p, 0, (size_t)nlist * 4, ctx->stream));
   hipLaunchKernelGGL(plan_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, probes, n,
-                     S.s_cnt.as<uint32_t>());
+                     S.s_cnt.as<uint32_t>(), ivf->t_off.as<uint32_t>());
   hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, S.s_cnt.as<uint32_t>(),
                      ivf->t_off.as<uint32_t>(), ivf->t_len.as<uint32_t>(), nlist, segb, Q, S.s_eoff.as<uint32_t>(),
                      S.s_ioff.as<uint32_t>(), S.s_fill.as<uint32_t>(), scal + 2, scal + 3,
                      (unsigned long long*)(scal + 4));
   hipLaunchKernelGGL(plan_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, probes, n, np,
-                     S.s_eoff.as<uint32_t>(), S.s_fill.as<uint32_t>(), S.s_entries.as<uint2>());
+                     S.s_eoff.as<uint32_t>(), S.s_fill.as<uint32_t>(), S.s_entries.as<uint2>(), ivf->t_off.as<uint32_t>());
   if (ivf->ctx->profiling && events) (void)hipEventRecord(S.sev[3], ctx->stream);
   ScanLaunch s{ivf->pool.view(), ivf->t_off.as<uint32_t>(), ivf->t_blocks.as<uint32_t>(), nlist,
                S.s_eoff.as<uint32_t>(), S.s_ioff.as<uint32_t>(), S.s_entries.as<uint2>(), scal + 2,
@@ -648,12 +648,13 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   auto plan = [&](const uint32_t* pr, uint32_t n, uint32_t npp, uint32_t sb, unsigned long long* stats,
                   uint32_t lsplit = 0xFFFFFFFFu, uint32_t sb_tail = 0) {
     // cnt[] is zero on entry: cleared by prep_queries_kernel for the first plan, by plan_scan_kernel for the second
-    hipLaunchKernelGGL(plan_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, pr, n, S.s_cnt.as<uint32_t>());
+    hipLaunchKernelGGL(plan_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, pr, n, S.s_cnt.as<uint32_t>(),
+                       lists.off);
     hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, S.s_cnt.as<uint32_t>(), lists.off,
                        ivf->t_len.as<uint32_t>(), nlist, sb, Q, S.s_eoff.as<uint32_t>(), S.s_ioff.as<uint32_t>(),
                        S.s_fill.as<uint32_t>(), scal + 2, scal + 3, stats, S.s_cnt.as<uint32_t>(), lsplit, sb_tail);
     hipLaunchKernelGGL(plan_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, pr, n, npp,
-                       S.s_eoff.as<uint32_t>(), S.s_fill.as<uint32_t>(), S.s_entries.as<uint2>());
+                       S.s_eoff.as<uint32_t>(), S.s_fill.as<uint32_t>(), S.s_entries.as<uint2>(), lists.off);
   };
   MfmaScanArgs a{};
   const bool half_rows = ivf->f16 || ivf->pool.half != nullptr;  // the filter reads fp16 rows (stored or mirrored)
@@ -1038,7 +1039,8 @@ int ivf_shared_thresholds(fvdb_ivf* ivf, const Env& E, const float* q_dev, const
 }
 
 // thr = min over the ranks' U arrays + this rank's own error bound
-int ivf_thr_combine(fvdb_ivf* ivf, const Env& E, const float* u_all, uint32_t W, uint32_t B, float* thr_out) {
+int ivf_thr_combine(fvdb_ivf* ivf, const Env& E, const float* u_all, uint32_t W, uint32_t B, float* thr_out,
+                    bool loopback_fill = false) {
   fvdb_ctx* ctx = E.ctx;
   IvfScratch& S = *E.S;
   if (!ivf->d_xmax.p) {
@@ -1047,6 +1049,8 @@ int ivf_thr_combine(fvdb_ivf* ivf, const Env& E, const float* u_all, uint32_t W,
   }
   hipLaunchKernelGGL(thr_combine_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, u_all, W, B, S.s_qn2.as<float>(),
                      ivf->d_xmax.as<uint32_t>(), (float)ivf->dpad, ivf->f16 ? 0 : (ivf->pool.half ? 1 : 2), thr_out);
+  if (loopback_fill)
+    hipLaunchKernelGGL(thr_loopback_fill_kernel, dim3(1), dim3(1024), 0, ctx->stream, thr_out, S.s_qn2.as<float>(), B);
   HIPCHK(ctx, hipGetLastError());
   return FVDB_OK;
 }
@@ -1694,11 +1698,11 @@ static int shared_thresholds_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, co
   return slot_done(ivf, E, ivf_shared_thresholds(ivf, E, q_dev, probes_dev, B, k, np, u_out));
 }
 static int thr_combine_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* u_all, uint32_t W, uint32_t B,
-                            float* thr_out) {
+                            float* thr_out, bool loopback_fill) {
   Env E{};
   int rc = slot_env(ivf, on, slot, &E);
   if (rc) return rc;
-  return slot_done(ivf, E, ivf_thr_combine(ivf, E, u_all, W, B, thr_out));
+  return slot_done(ivf, E, ivf_thr_combine(ivf, E, u_all, W, B, thr_out, loopback_fill));
 }
 static int search_probes_thr_slot(fvdb_ivf* ivf, fvdb_ctx* on, uint32_t slot, const float* q_dev, const uint32_t* probes_dev,
                                   const float* thr_dev, uint32_t B, uint32_t k, uint32_t nprobe, uint64_t* out_ids_dev,

@@ -711,6 +711,36 @@ __global__ void thr_combine_kernel(const float* __restrict__ u_all, uint32_t W, 
   for (uint32_t w = 0; w < W; ++w) m = fminf(m, u_all[(size_t)w * n + i]);
   thr[i] = m + mfma_error_bound(__uint_as_float(*xmax_bits), qn[i], d, rows_f16);
 }
+// Loopback communicator only (capacity planning, fvdb_comm_create_loopback): the peers that would have supplied the
+// thresholds of the queries whose list this rank does not own do not exist, so those entries get a typical one — the
+// mean of the known (thr + |q|^2), i.e. a typical squared distance of the (k+6)-th neighbour, minus the query's |q|^2.
+__global__ __launch_bounds__(1024) void thr_loopback_fill_kernel(float* __restrict__ thr, const float* __restrict__ qn, uint32_t n) {
+  __shared__ float s_sum[1024];
+  __shared__ uint32_t s_cnt[1024];
+  float sum = 0.0f;
+  uint32_t cnt = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+    const float t = thr[i];
+    if (t < __builtin_huge_valf()) {
+      sum += t + qn[i];
+      cnt += 1;
+    }
+  }
+  s_sum[threadIdx.x] = sum;
+  s_cnt[threadIdx.x] = cnt;
+  __syncthreads();
+  for (uint32_t o = 512; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
+      s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (s_cnt[0] == 0) return;
+  const float typ = s_sum[0] / (float)s_cnt[0];
+  for (uint32_t i = threadIdx.x; i < n; i += 1024)
+    if (!(thr[i] < __builtin_huge_valf())) thr[i] = typ - qn[i];
+}
 __global__ void fill_f32_kernel(float* __restrict__ p, uint32_t n, float v) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

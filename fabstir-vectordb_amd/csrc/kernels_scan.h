@@ -450,11 +450,14 @@ __global__ __launch_bounds__(256) void merge_keys_kernel(const uint64_t* __restr
 // -----------------------------------------------------------------------------------------
 // plan kernels: probes[B][nprobe] -> per-list entries + work-item prefix sums
 // -----------------------------------------------------------------------------------------
-__global__ void plan_count_kernel(const uint32_t* __restrict__ probes, uint32_t n, uint32_t* __restrict__ cnt) {
+// list_off (optional): lists with no blocks on this device are not planned at all — on a rank of a W-rank job that is
+// (W-1)/W of the probes of the W*B queries it scans
+__global__ void plan_count_kernel(const uint32_t* __restrict__ probes, uint32_t n, uint32_t* __restrict__ cnt,
+                                  const uint32_t* __restrict__ list_off = nullptr) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const uint32_t L = probes[i];
-    if (L != kInf32) atomicAdd(cnt + L, 1u);
+    if (L != kInf32 && (!list_off || list_off[L + 1] != list_off[L])) atomicAdd(cnt + L, 1u);
   }
 }
 
@@ -534,11 +537,11 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const uint32_t* __restr
 
 __global__ void plan_fill_kernel(const uint32_t* __restrict__ probes, uint32_t n, uint32_t nprobe,
                                  const uint32_t* __restrict__ entry_off, uint32_t* __restrict__ fill,
-                                 uint2* __restrict__ entries) {
+                                 uint2* __restrict__ entries, const uint32_t* __restrict__ list_off = nullptr) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const uint32_t L = probes[i];
-    if (L != kInf32) {
+    if (L != kInf32 && (!list_off || list_off[L + 1] != list_off[L])) {
       const uint32_t p = atomicAdd(fill + L, 1u);
       entries[entry_off[L] + p] = make_uint2(i / nprobe, i % nprobe);
     }

@@ -126,6 +126,13 @@ class Comm:
         ctx.check(ctx.lib.fvdb_comm_create_hosted(ctx.h, world, rank, C.cast(fn, C.c_void_p), None, C.byref(h)))
         return cls(ctx, h, world, rank, keep=fn)
 
+    @classmethod
+    def loopback(cls, ctx, world, rank=0):
+        """Capacity planning on one GPU (fvdb_comm_create_loopback): rank `rank` of a pretended `world`-rank job."""
+        h = C.c_void_p()
+        ctx.check(ctx.lib.fvdb_comm_create_loopback(ctx.h, world, rank, C.byref(h)))
+        return cls(ctx, h, world, rank)
+
     def all_gather_dev(self, send_dev, recv_dev, nbytes, on=None):
         self.ctx.check(self.ctx.lib.fvdb_comm_all_gather_dev(self.h, on, send_dev, recv_dev, nbytes))
 

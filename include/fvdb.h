@@ -359,6 +359,11 @@ typedef int (*fvdb_exchange_fn)(void* user, int op, const void* send_host, void*
 int fvdb_comm_unique_id(void* out128);
 int fvdb_comm_create(fvdb_ctx* ctx, const void* id128, int world, int rank, fvdb_comm** out);
 int fvdb_comm_create_hosted(fvdb_ctx* ctx, int world, int rank, fvdb_exchange_fn fn, void* user, fvdb_comm** out);
+/* Capacity planning on ONE GPU: a communicator of `world` ranks whose exchanges are device-to-device copies of this
+ * rank's own blocks (every peer is pretended to have sent what this rank sent).  Results are meaningless; the step's
+ * kernels, buffer sizes and stream ordering are exactly those of rank `rank` in a real `world`-rank job, so its time is
+ * the per-rank step time less the fabric.  bench.py --emulate-world N. */
+int fvdb_comm_create_loopback(fvdb_ctx* ctx, int world, int rank, fvdb_comm** out);
 void fvdb_comm_destroy(fvdb_comm* comm);
 int fvdb_comm_rank(fvdb_comm* comm);
 int fvdb_comm_world(fvdb_comm* comm);
