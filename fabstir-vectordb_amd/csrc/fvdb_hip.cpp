@@ -1628,7 +1628,9 @@ static int search_common(fvdb_ivf* ivf, const Env& E, const float* q_dev, uint32
       if (rc) return rc;
     }
     if (probes_only) continue;
-    rc = run_fine(ivf, E, qpad, b, k, np, probes, out_ids ? out_ids + (size_t)o * k : nullptr,
+    Env Eo = E;
+    if (E.given_thr) Eo.given_thr = E.given_thr + o;  // agreed thresholds are indexed like the queries
+    rc = run_fine(ivf, Eo, qpad, b, k, np, probes, out_ids ? out_ids + (size_t)o * k : nullptr,
                   out_dist ? out_dist + (size_t)o * k : nullptr, out_counts ? out_counts + o : nullptr,
                   out_keys ? out_keys + (size_t)o * k : nullptr, all ? ROLE_ALL : ROLE_LIST);
     if (rc) return rc;
