@@ -89,6 +89,14 @@ SIGNATURES = {
     "fvdb_graph_destroy": (None, [vp]),
     "fvdb_graph_upload": (i32, [vp, u32, u32p, C.POINTER(C.c_uint8), u32p, u32p, u32]),
     "fvdb_graph_set_deleted": (i32, [vp, u32, i32]),
+    "fvdb_graph_configure": (i32, [vp, u32, u32]),
+    "fvdb_graph_append_nodes": (i32, [vp, u32, u32, u32p]),
+    "fvdb_graph_insert_linked": (i32, [vp, u32, u32, u32, i32, u32p, vp]),
+    "fvdb_graph_set_lists": (i32, [vp, u32, u32p, u32p, u32p, u32p]),
+    "fvdb_graph_set_entry": (i32, [vp, u32, u32]),
+    "fvdb_graph_entry": (i32, [vp, u32p, u32p]),
+    "fvdb_graph_download": (i32, [vp, u32p, u32p, u64, u64p]),
+    "fvdb_graph_upload_bytes": (u64, [vp]),
     "fvdb_graph_search_dev": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp]),
     "fvdb_graph_search_dev_slot": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp, vp, vp]),
     "fvdb_ctx_device": (i32, [vp]),

@@ -2,7 +2,7 @@
 //   hipcc -x hip -O3 -ffp-contract=off --offload-arch=gfx950
 // Host side here is plumbing: memory, launch order, list bookkeeping.  All arithmetic on
 // vectors happens in the kernels; there is no CPU fallback anywhere in this library.
-#include "../../include/fvdb.h"
+#include "fvdb_internal.h"
 
 #include <algorithm>
 #include <atomic>
@@ -18,8 +18,6 @@
 #include <vector>
 
 #include "common.h"
-#include "kernels_graph.h"
-#include "kernels_graph_fast.h"
 #include "kernels_misc.h"
 #include "kernels_scan.h"
 #include "kernels_coarse.h"
@@ -29,83 +27,6 @@
 
 using namespace fvdb;
 
-namespace {
-
-struct DBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  hipError_t ensure(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    size_t want = std::max<size_t>(bytes + bytes / 4, 256);
-    hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) cap = want;
-    return e;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-  template <typename T>
-  T* as() const { return (T*)p; }
-};
-
-struct HBuf {  // pinned host staging
-  void* p = nullptr;
-  size_t cap = 0;
-  hipError_t ensure(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-    cap = 0;
-    size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-    if (e == hipSuccess) cap = want;
-    return e;
-  }
-  void release() {
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-};
-
-}  // namespace
-
-struct fvdb_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  int num_cus = 256;
-  std::string err;   // last failure; written under err_mu (searches may fail on several host threads)
-  std::mutex err_mu;
-  void set_err(std::string m) {
-    std::lock_guard<std::mutex> lk(err_mu);
-    err = std::move(m);
-  }
-  HBuf h_stage;     // host->device staging for host-pointer entry points
-  int profiling = 0;
-};
-
-#define HIPCHK(ctx, call)                                                                     \
-  do {                                                                                        \
-    hipError_t e_ = (call);                                                                   \
-    if (e_ != hipSuccess) {                                                                   \
-      (ctx)->set_err(std::string(#call) + ": " + hipGetErrorString(e_));                      \
-      return e_ == hipErrorOutOfMemory ? FVDB_E_OOM : FVDB_E_HIP;                             \
-    }                                                                                         \
-  } while (0)
-
-#define FAIL(ctx, code, msg) \
-  do {                       \
-    (ctx)->set_err(msg);     \
-    return (code);           \
-  } while (0)
-
-static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // A pool of 64-row blocks in HBM (layout: common.h PoolView).
 struct Pool {
@@ -288,44 +209,6 @@ struct Env {
 inline IvfScratch& slot_scratch(fvdb_ivf* ivf, uint32_t slot) { return slot == 0 ? *ivf : ivf->spare[slot - 1]; }
 }  // namespace
 
-struct fvdb_store {
-  fvdb_ctx* ctx = nullptr;
-  uint32_t d = 0, dpad = 0;
-  uint64_t rows = 0, cap = 0;
-  float* data = nullptr;  // [cap][dpad]
-  DBuf s_q, s_cand, s_out, s_in;
-};
-
-struct fvdb_graph {
-  fvdb_store* store = nullptr;
-  uint32_t n = 0, entry = 0, top_level = 0, n_slots = 0;
-  DBuf d_level, d_deleted, d_slot_of, d_slot_start, d_adj, d_adj0;
-  uint32_t stride0 = 0;
-  DBuf s_q, d_counters;
-  static constexpr uint32_t kSlots = 16;  // batches that may be in flight at once, each on its own stream
-  DBuf s_visited[kSlots], s_touched[kSlots];
-  uint32_t vis_B[kSlots] = {}, vis_words = 0, vis_tcap = 0, vis_stride = 0;
-  bool uploaded = false;
-  // profiling: HIP events around the last launches of the traversal kernel (ring of 64)
-  std::vector<uint8_t> h_deleted;  // host copy of the flags: searches skip the per-neighbour flag load when none is set
-  uint64_t n_deleted = 0;
-  hipEvent_t kev[64][2] = {};
-  uint32_t kev_n = 0;   // launches recorded since the last fvdb_graph_kernel_times call
-  std::mutex mu;        // launch bookkeeping: searches in different slots may come from different host threads
-  uint64_t last_rows = 0;
-};
-
-struct fvdb_scorer {
-  fvdb_store* store = nullptr;
-  hipStream_t stream = nullptr;  // private stream: scorers of different host threads run concurrently
-  uint32_t max_B = 0, max_C = 0;
-  float* d_q = nullptr;        // [max_B][dpad]
-  uint32_t* h_cand = nullptr;  // pinned, mapped
-  float* h_dist = nullptr;     // pinned, mapped
-  uint32_t* d_cand = nullptr;  // device aliases of the mapped buffers
-  float* d_dist = nullptr;
-  DBuf s_rows, s_in;  // private scratch: scorers are driven from different host threads
-};
 
 // ---------------------------------------------------------------------------------------------
 // launch helpers
@@ -2509,333 +2392,6 @@ int fvdb_scorer_run(fvdb_scorer* sc, uint32_t B, uint32_t C) {
   return fvdb_scorer_wait(sc);
 }
 
-// =============================================================================================
-// device-resident graph traversal
-// =============================================================================================
-int fvdb_graph_create(fvdb_store* s, fvdb_graph** out) {
-  if (!s || !out) return FVDB_E_INVALID;
-  *out = nullptr;
-  fvdb_graph* g = new (std::nothrow) fvdb_graph();
-  if (!g) return FVDB_E_OOM;
-  g->store = s;
-  *out = g;
-  return FVDB_OK;
-}
-
-void fvdb_graph_destroy(fvdb_graph* g) {
-  if (g)
-    for (auto& e : g->kev)
-      for (auto& x : e)
-        if (x) (void)hipEventDestroy(x);
-  if (!g) return;
-  (void)hipSetDevice(g->store->ctx->device);
-  (void)hipStreamSynchronize(g->store->ctx->stream);
-  DBuf* bufs[] = {&g->d_level, &g->d_deleted, &g->d_slot_of, &g->d_slot_start, &g->d_adj, &g->d_adj0, &g->s_q, &g->d_counters};
-  for (auto& b : g->s_visited) b.release();
-  for (auto& b : g->s_touched) b.release();
-  for (DBuf* b : bufs) b->release();
-  delete g;
-}
-
-int fvdb_graph_upload(fvdb_graph* g, uint32_t n, const uint32_t* levels, const uint8_t* deleted,
-                      const uint32_t* slot_start, const uint32_t* adj, uint32_t entry_node) {
-  fvdb_ctx* ctx = g->store->ctx;
-  if (n == 0 || n > g->store->rows || entry_node >= n) FAIL(ctx, FVDB_E_INVALID, "graph does not match the store");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  std::vector<uint32_t> slot_of(n), del32(n);
-  uint32_t slots = 0;
-  for (uint32_t i = 0; i < n; ++i) {
-    slot_of[i] = slots;
-    slots += levels[i] + 1;
-    del32[i] = deleted ? deleted[i] : 0;
-  }
-  for (uint32_t sidx = 0; sidx < slots; ++sidx)
-    if (slot_start[sidx + 1] - slot_start[sidx] > 64) FAIL(ctx, FVDB_E_UNSUPPORTED, "neighbour list longer than 64");
-  const uint32_t edges = slot_start[slots];
-  // layer 0 in fixed-stride form [count, neighbours...]: the walk spends nearly all its hops there
-  uint32_t max0 = 0;
-  for (uint32_t i = 0; i < n; ++i) max0 = std::max(max0, slot_start[slot_of[i] + 1] - slot_start[slot_of[i]]);
-  const uint32_t stride0 = max0 + 1;
-  std::vector<uint32_t> adj0((size_t)n * stride0, 0u);
-  for (uint32_t i = 0; i < n; ++i) {
-    const uint32_t a0 = slot_start[slot_of[i]], c = slot_start[slot_of[i] + 1] - a0;
-    adj0[(size_t)i * stride0] = c;
-    for (uint32_t e = 0; e < c; ++e) adj0[(size_t)i * stride0 + 1 + e] = adj[a0 + e];
-  }
-  HIPCHK(ctx, g->d_adj0.ensure(adj0.size() * 4));
-  HIPCHK(ctx, hipMemcpyAsync(g->d_adj0.p, adj0.data(), adj0.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  g->stride0 = stride0;
-  HIPCHK(ctx, g->d_level.ensure((size_t)n * 4));
-  HIPCHK(ctx, g->d_deleted.ensure((size_t)n * 4));
-  HIPCHK(ctx, g->d_slot_of.ensure((size_t)n * 4));
-  HIPCHK(ctx, g->d_slot_start.ensure((size_t)(slots + 1) * 4));
-  HIPCHK(ctx, g->d_adj.ensure(std::max<size_t>(edges, 1) * 4));
-  HIPCHK(ctx, hipMemcpyAsync(g->d_level.p, levels, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(g->d_deleted.p, del32.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(g->d_slot_of.p, slot_of.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(g->d_slot_start.p, slot_start, (size_t)(slots + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (edges) HIPCHK(ctx, hipMemcpyAsync(g->d_adj.p, adj, (size_t)edges * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  g->h_deleted.assign(n, 0);
-  g->n_deleted = 0;
-  for (uint32_t i = 0; i < n; ++i)
-    if (del32[i]) {
-      g->h_deleted[i] = 1;
-      g->n_deleted += 1;
-    }
-  g->n = n;
-  g->entry = entry_node;
-  g->top_level = levels[entry_node];
-  g->n_slots = slots;
-  g->uploaded = true;
-  for (auto& v : g->vis_B) v = 0;  // node count may have changed: re-size (and re-zero) the visited bitmaps
-  return FVDB_OK;
-}
-
-int fvdb_graph_set_deleted(fvdb_graph* g, uint32_t node, int deleted) {
-  fvdb_ctx* ctx = g->store->ctx;
-  if (!g->uploaded || node >= g->n) FAIL(ctx, FVDB_E_NOT_FOUND, "no such node");
-  const uint32_t v = deleted ? 1u : 0u;
-  if (g->h_deleted[node] != (uint8_t)v) {
-    g->n_deleted += v ? 1 : -1;
-    g->h_deleted[node] = (uint8_t)v;
-  }
-  HIPCHK(ctx, hipMemcpyAsync(g->d_deleted.as<uint32_t>() + node, &v, 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return FVDB_OK;
-}
-
-int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_t k, uint32_t ef,
-                          uint32_t* out_nodes_dev, float* out_dist_dev, uint32_t* out_counts_dev,
-                          uint32_t* out_status_dev) {
-  return fvdb_graph_search_dev_slot(g, nullptr, 0, q_dev, B, k, ef, out_nodes_dev, out_dist_dev, out_counts_dev,
-                                    out_status_dev);
-}
-
-int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t k,
-                               uint32_t ef, uint32_t* out_nodes_dev, float* out_dist_dev, uint32_t* out_counts_dev,
-                               uint32_t* out_status_dev) {
-  fvdb_store* s = g->store;
-  fvdb_ctx* ctx = on ? on : s->ctx;
-  if (slot >= fvdb_graph::kSlots) FAIL(ctx, FVDB_E_INVALID, "slot out of range");
-  if (on && on->device != s->ctx->device) FAIL(ctx, FVDB_E_INVALID, "context of another device");
-  if (s->d != s->dpad && slot != 0) FAIL(ctx, FVDB_E_UNSUPPORTED, "padded dimensions use slot 0 only");
-  if (!g->uploaded) FAIL(ctx, FVDB_E_INVALID, "graph not uploaded");
-  if (k == 0 || ef == 0 || ef > 4096) FAIL(ctx, FVDB_E_UNSUPPORTED, "ef must be in 1..4096");
-  if (B == 0) return FVDB_OK;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  std::lock_guard<std::mutex> lk(g->mu);
-  const float* qd = q_dev;
-  if (s->d != s->dpad) {
-    HIPCHK(ctx, g->s_q.ensure((size_t)B * s->dpad * 4));
-    hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv((uint64_t)B * s->dpad, 256)), dim3(256), 0, ctx->stream, q_dev, s->d,
-                       s->dpad, (uint64_t)B, g->s_q.as<float>());
-    qd = g->s_q.as<float>();
-  }
-  // visited-log capacity per query (FVDB_GRAPH_TCAP: test hook that forces the overflow -> host-walk fallback)
-  const uint32_t words = (g->n + 31) / 32;
-  const uint32_t tcap = getenv("FVDB_GRAPH_TCAP") ? std::max(1, atoi(getenv("FVDB_GRAPH_TCAP"))) : 8192;
-  // visited set per query: one byte per node while a batch's maps stay under 1 GiB (no atomics, see
-  // kernels_graph_fast.h), else one bit per node; the row stride is the same for both views
-  static const bool no_bytes = getenv("FVDB_GRAPH_BITMAP") != nullptr;  // tuning aid / A-B (byte map: ~2.5 % faster, 8x the memory)
-  const uint32_t vbytes = ((g->n + 63) / 64) * 64;
-  const bool bytemap = !no_bytes && (uint64_t)vbytes * std::max<uint32_t>(B, 1024) <= (1ull << 30);
-  const uint32_t vstride = bytemap ? vbytes : words * 4;
-  if (words != g->vis_words || tcap != g->vis_tcap || vstride != g->vis_stride) {
-    for (auto& v : g->vis_B) v = 0;
-    g->vis_words = words;
-    g->vis_tcap = tcap;
-    g->vis_stride = vstride;
-  }
-  if (B > g->vis_B[slot]) {  // the maps are left all-zero by every search: zero once
-    HIPCHK(ctx, g->s_visited[slot].ensure((size_t)B * vstride));
-    HIPCHK(ctx, hipMemsetAsync(g->s_visited[slot].p, 0, g->s_visited[slot].cap, ctx->stream));
-    HIPCHK(ctx, g->s_touched[slot].ensure((size_t)B * tcap * 4));
-    g->vis_B[slot] = B;
-  }
-  // candidate-heap slots of the exact-heap search: it holds every admitted node not yet expanded; a query that
-  // overflows it goes to the host walk (data with many duplicate vectors fills it quickly, so it stays generous:
-  // at the default tile size the sorted-register kernel's LDS need is larger anyway)
-  static const int cand_env = getenv("FVDB_GRAPH_CAND_CAP") ? atoi(getenv("FVDB_GRAPH_CAND_CAP")) : 0;  // tuning aid
-  const uint32_t cand_cap = cand_env > 0 ? (uint32_t)cand_env : std::max<uint32_t>(1024, 8 * ef);
-  const size_t lds = graph_lds_bytes(s->dpad, ef, cand_cap);
-  if (lds > 160 * 1024) FAIL(ctx, FVDB_E_UNSUPPORTED, "dimension / ef too large for the on-chip traversal state");
-  static const bool lds_heaps = getenv("FVDB_GRAPH_LDS_HEAPS") != nullptr;  // tuning aid: lane-0 heaps for any ef
-  const bool rh = ef <= 63 && !lds_heaps;
-  if (lds > 48 * 1024) {
-    if (rh) HIPCHK(ctx, hipFuncSetAttribute((const void*)hnsw_search_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    else HIPCHK(ctx, hipFuncSetAttribute((const void*)hnsw_search_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
-  GraphView gv{s->data, g->d_level.as<uint32_t>(), g->d_deleted.as<uint32_t>(), g->d_slot_of.as<uint32_t>(),
-               g->d_slot_start.as<uint32_t>(), g->d_adj.as<uint32_t>(), g->d_adj0.as<uint32_t>(), g->stride0, g->n,
-               s->dpad, g->entry, g->top_level, g->n_deleted ? 1u : 0u, nullptr, nullptr};
-  if (!g->d_counters.p) {
-    HIPCHK(ctx, g->d_counters.ensure(16));
-    HIPCHK(ctx, hipMemsetAsync(g->d_counters.p, 0, 16, ctx->stream));
-  }
-  gv.counters = (unsigned long long*)g->d_counters.p;
-#ifdef FVDB_GRAPH_STAMPS
-  static unsigned long long* d_stamps = nullptr;
-  constexpr size_t kStampWords = 8 + 3 * 16384 + 4;  // 8 sums, then per query (cycles, hops, start tick) of the last launch
-  if (!d_stamps) {
-    (void)hipMalloc(&d_stamps, kStampWords * 8);
-    (void)hipMemset(d_stamps, 0, kStampWords * 8);
-  }
-  gv.stamps = d_stamps;
-  {
-    (void)hipDeviceSynchronize();
-    std::vector<unsigned long long> h(kStampWords);
-    (void)hipMemcpy(h.data(), d_stamps, kStampWords * 8, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[graph stamps, cumulative] s0 %llu s1 %llu s2 %llu s3 %llu | rows %llu rounds %llu hops %llu total %llu | score: issue %llu "
-            "first-block wait+products %llu other-block products %llu adds %llu\n",
-            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8 + 3 * 16384], h[8 + 3 * 16384 + 1], h[8 + 3 * 16384 + 2], h[8 + 3 * 16384 + 3]);
-    std::vector<unsigned long long> cyc, hp, rt;
-    {
-      // placement: HW_ID bits [3:0] wave, [5:4] simd, [11:8] cu, [12] sh, [15:13] se; top nibble = XCC
-      std::map<unsigned, unsigned> per_cu, per_simd;
-      unsigned late = 0;
-      unsigned long long first = ~0ull;
-      for (uint32_t q = 0; q < 16384; ++q)
-        if (h[8 + 3 * q]) first = std::min(first, h[8 + 3 * q + 1]);
-      for (uint32_t q = 0; q < 16384; ++q)
-        if (h[8 + 3 * q]) {
-          const unsigned hw = (unsigned)((h[8 + 3 * q] >> 32) & 0x0FFFFFFFu), xcc = (unsigned)(h[8 + 3 * q] >> 60);
-          const unsigned cu = (xcc << 16) | (hw & 0xFF00u);
-          per_cu[cu]++;
-          per_simd[(cu << 2) | ((hw >> 4) & 3)]++;
-          if (h[8 + 3 * q + 1] - first > 10000) late++;
-          h[8 + 3 * q] &= 0xFFFFFFFFull;
-        }
-      unsigned mx_cu = 0, mx_simd = 0;
-      for (auto& kv : per_cu) mx_cu = std::max(mx_cu, kv.second);
-      for (auto& kv : per_simd) mx_simd = std::max(mx_simd, kv.second);
-      fprintf(stderr, "[graph stamps, placement] CUs used %zu (max waves on one CU %u), SIMDs used %zu (max on one %u), waves starting > 100 us late: %u\n",
-              per_cu.size(), mx_cu, per_simd.size(), mx_simd, late);
-    }
-    for (uint32_t q = 0; q < 16384; ++q)
-      if (h[8 + 3 * q]) {
-        cyc.push_back(h[8 + 3 * q]);
-        hp.push_back(h[8 + 3 * q + 1]);
-        rt.push_back(h[8 + 3 * q + 2]);
-      }
-    if (!cyc.empty()) {
-      double csum = 0, rsum = 0;
-      for (size_t i = 0; i < cyc.size(); ++i) {
-        csum += (double)cyc[i];
-        rsum += (double)rt[i];
-      }
-      // hp = start tick (100 MHz), rt = lifetime ticks
-      unsigned long long t0 = ~0ull, t1 = 0;
-      for (size_t i = 0; i < cyc.size(); ++i) {
-        t0 = std::min(t0, hp[i]);
-        t1 = std::max(t1, hp[i] + rt[i]);
-      }
-      std::vector<unsigned long long> st;
-      for (size_t i = 0; i < cyc.size(); ++i) st.push_back(hp[i] - t0);
-      std::sort(cyc.begin(), cyc.end());
-      std::sort(st.begin(), st.end());
-      std::sort(rt.begin(), rt.end());
-      const size_t n = cyc.size();
-      fprintf(stderr, "[graph stamps, last launch] queries %zu  cycles p50 %llu max %llu | wave lifetime us p50 %.1f p99 %.1f max %.1f | clock %.2f GHz | "
-              "first start .. last end %.1f us; starts us: p25 %.1f p50 %.1f p75 %.1f p90 %.1f max %.1f\n", n, cyc[n / 2], cyc[n - 1],
-              rt[n / 2] / 100.0, rt[n * 99 / 100] / 100.0, rt[n - 1] / 100.0, csum / rsum / 10.0, (t1 - t0) / 100.0, st[n / 4] / 100.0,
-              st[n / 2] / 100.0, st[n * 3 / 4] / 100.0, st[n * 9 / 10] / 100.0, st[n - 1] / 100.0);
-    }
-    (void)hipMemset(d_stamps, 0, kStampWords * 8);
-  }
-#endif
-  hipEvent_t* ev = nullptr;
-  if (s->ctx->profiling) {  // the store's context carries the switch, whichever stream the launch goes to
-    ev = g->kev[g->kev_n & 63];
-    if (!ev[0]) {
-      (void)hipEventCreate(&ev[0]);
-      (void)hipEventCreate(&ev[1]);
-    }
-    (void)hipEventRecord(ev[0], ctx->stream);
-  }
-  // ef <= 63: the sorted-register kernel; a query in which two heap members meet with equal distances is re-run by
-  // the same wave with the reference's heaps restated (exact on ties)
-  static const bool no_fast = getenv("FVDB_GRAPH_NO_FAST") != nullptr;  // tuning aid / A-B
-  static const int fast_r = getenv("FVDB_GRAPH_FAST_R") ? atoi(getenv("FVDB_GRAPH_FAST_R")) : 0;
-  const uint32_t nb128 = (s->dpad + 127) / 128;
-  const bool fast = !no_fast && rh && nb128 <= 8 && g->n < 0x80000000u;
-  if (fast) {
-    int R = nb128 <= 3 ? 16 : (nb128 == 4 ? 12 : (nb128 <= 6 ? 8 : 6));  // rows per scoring round: registers R*NB*2
-    if (nb128 == 3 && (fast_r == 8 || fast_r == 12)) R = fast_r;
-    const uint32_t wave_lds = (uint32_t)((std::max(graph_fast_lds_bytes((uint32_t)R), lds) + 15) & ~(size_t)15);
-#define FVDB_FAST_LAUNCH_V(NB_, R_, BY_)                                                                                   \
-  do {                                                                                                                    \
-    if (4 * wave_lds > 48 * 1024)                                                                                         \
-      HIPCHK(ctx, hipFuncSetAttribute((const void*)hnsw_search_fast_kernel<NB_, R_, BY_>,                                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * wave_lds)));                  \
-    hipLaunchKernelGGL((hnsw_search_fast_kernel<NB_, R_, BY_>), dim3(cdiv(B, 4)), dim3(256), 4 * wave_lds, ctx->stream,   \
-                       gv, qd, B, k, ef, cand_cap, wave_lds, g->s_visited[slot].as<uint8_t>(), vstride, words,            \
-                       g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev, out_counts_dev,              \
-                       out_status_dev);                                                                                   \
-  } while (0)
-#define FVDB_FAST_LAUNCH(NB_, R_)                  \
-  do {                                             \
-    if (bytemap) FVDB_FAST_LAUNCH_V(NB_, R_, true); \
-    else FVDB_FAST_LAUNCH_V(NB_, R_, false);       \
-  } while (0)
-    if (4 * (size_t)wave_lds > 160 * 1024) FAIL(ctx, FVDB_E_UNSUPPORTED, "dimension / ef too large for the on-chip traversal state");
-    switch (nb128) {
-      case 1: FVDB_FAST_LAUNCH(1, 16); break;
-      case 2: FVDB_FAST_LAUNCH(2, 16); break;
-      case 3:
-        if (R == 8) FVDB_FAST_LAUNCH(3, 8);
-        else if (R == 12) FVDB_FAST_LAUNCH(3, 12);
-        else FVDB_FAST_LAUNCH(3, 16);
-        break;
-      case 4: FVDB_FAST_LAUNCH(4, 12); break;
-      case 5:
-      case 6: FVDB_FAST_LAUNCH(6, 8); break;
-      default: FVDB_FAST_LAUNCH(8, 6); break;
-    }
-#undef FVDB_FAST_LAUNCH_V
-#undef FVDB_FAST_LAUNCH
-  } else if (rh) {
-    hipLaunchKernelGGL(hnsw_search_kernel<true>, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
-                       g->s_visited[slot].as<uint32_t>(), vstride / 4, g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
-                       out_counts_dev, out_status_dev);
-  } else {
-    hipLaunchKernelGGL(hnsw_search_kernel<false>, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
-                       g->s_visited[slot].as<uint32_t>(), vstride / 4, g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
-                       out_counts_dev, out_status_dev);
-  }
-  if (ev) {
-    (void)hipEventRecord(ev[1], ctx->stream);
-    g->kev_n += 1;
-  }
-  HIPCHK(ctx, hipGetLastError());
-  return FVDB_OK;
-}
-
-int fvdb_graph_kernel_times(fvdb_graph* g, float* ms_sum, uint32_t* launches, uint64_t* rows_scored, uint64_t* hops) {
-  fvdb_ctx* ctx = g->store->ctx;
-  *ms_sum = 0.0f;
-  *launches = 0;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  unsigned long long c[2] = {0, 0};
-  if (g->d_counters.p) {
-    HIPCHK(ctx, hipMemcpy(c, g->d_counters.p, 16, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemset(g->d_counters.p, 0, 16));
-  }
-  if (rows_scored) *rows_scored = c[0];
-  if (hops) *hops = c[1];
-  const uint32_t n = std::min<uint32_t>(g->kev_n, 64);
-  for (uint32_t i = 0; i < n; ++i) {
-    hipEvent_t* ev = g->kev[(g->kev_n - 1 - i) & 63];
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) {
-      *ms_sum += ms;
-      *launches += 1;
-    }
-  }
-  g->kev_n = 0;
-  return FVDB_OK;
-}
 
 }  // extern "C"
 

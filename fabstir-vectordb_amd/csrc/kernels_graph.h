@@ -16,7 +16,6 @@
 // first, and only queries in which two heap members met with equal distances (or ef > 64, or d > 1024) come here.
 #pragma once
 #include "common.h"
-#include "kernels_scan.h"
 
 #pragma clang fp contract(off)
 
@@ -26,11 +25,12 @@ struct GraphView {
   const float* rows;          // [n][dpad] row-major vectors (fvdb_store)
   const uint32_t* level;      // [n]
   const uint32_t* deleted;    // [n] 0/1
-  const uint32_t* slot_of;    // [n] index of the node's layer-0 slot
-  const uint32_t* slot_start; // [slots+1] offsets into adj
-  const uint32_t* adj;        // neighbour node indices, list order
-  const uint32_t* adj0;       // layer 0 again, fixed stride: adj0[node*stride0] = count, then the neighbours
-  uint32_t stride0;           //   (one dependent load instead of three on the layer that takes ~all hops)
+  // Adjacency, fixed stride on every layer so that an insert rewrites only the rows it touches (kernels_graph_build.h,
+  // fvdb_graph_set_lists): a row is [count, neighbours in list order ...].
+  const uint32_t* adj0;       // layer 0: row of node i at adj0[i * stride0]
+  const uint32_t* ubase;      // [n] first upper row of the node: layer l >= 1 lives at adjU[(ubase[i] + l - 1) * strideU]
+  const uint32_t* adjU;
+  uint32_t stride0, strideU;
   uint32_t n, dpad, entry, top_level;
   uint32_t any_deleted;       // 0: no node is flagged, the per-neighbour flag load is skipped
   unsigned long long* counters;  // [0] rows scored, [1] hops — summed over queries (roofline accounting)
@@ -436,10 +436,9 @@ __device__ __forceinline__ void hnsw_search_exact_body(const GraphView& g, const
           nb = (uint32_t)lane + 1 < g.stride0 ? row[lane + 1] : 0u;
           cnt = __builtin_amdgcn_readfirstlane(w);
         } else {
-          const uint32_t s = g.slot_of[node] + layer;
-          const uint32_t a0 = g.slot_start[s];
-          cnt = g.slot_start[s + 1] - a0;  // cnt <= 64 (host checks the degree cap)
-          if ((uint32_t)lane < cnt) nb = g.adj[a0 + lane];
+          const uint32_t* row = g.adjU + (size_t)(g.ubase[node] + layer - 1) * g.strideU;
+          cnt = __builtin_amdgcn_readfirstlane(row[0]);  // cnt <= 64 (host checks the degree cap)
+          if ((uint32_t)lane < cnt) nb = row[lane + 1];
         }
         bool fresh = false, keep = false;
         if ((uint32_t)lane < cnt) {
@@ -450,11 +449,8 @@ __device__ __forceinline__ void hnsw_search_exact_body(const GraphView& g, const
         const uint64_t fm = __ballot(fresh), km = __ballot(keep);
         const uint64_t lt = (1ull << lane) - 1;
         const uint32_t nf = __popcll(fm);
-        if (nT + nf > tcap) {
-          overflow = true;
-        } else if (fresh) {
-          tch[nT + __popcll(fm & lt)] = nb;
-        }
+        // a log that fills up stops growing: the layer's bitmap is then cleared whole instead of entry by entry
+        if (fresh && nT + nf <= tcap) tch[nT + __popcll(fm & lt)] = nb;
         nT += nf;
         np = __popcll(km);
         if (keep) pending[__popcll(km & lt)] = nb;  // list order preserved

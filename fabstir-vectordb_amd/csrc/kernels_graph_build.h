@@ -1,0 +1,1080 @@
+// kernels_graph_build.h — HNSWIndex::insert (src/hnsw/core.rs:226-378) resident on the GPU.
+//
+// One WORKGROUP (8 wavefronts, one per CU) executes one insert: the greedy descent (search_layer with ef = 1,
+// :284-290), search_layer(ef_construction) on every layer of the new node (:305), select_neighbors (:556-558),
+// the back-links and prune_neighbors_with_new_node (:588-624), against an adjacency that lives in HBM with a
+// fixed stride per (node, layer) so that an insert rewrites only the rows it touches.  Inserts are applied
+// strictly in order; the graph is the reference's node for node.
+//
+// Why the results cannot differ from the serial algorithm although the work is reorganised:
+//
+//  * Distances are pure functions of two rows (the reference's left-to-right f32 fold, computed exactly as in
+//    kernels_graph_fast.h: coalesced loads, products transposed through LDS, a per-lane sequential add chain).
+//    A search round therefore scores the unvisited neighbours of SEVERAL candidates at once — the kSpec nearest
+//    unexpanded ones — on all eight waves, and wave 0 then REPLAYS the reference's loop (pop, visit the neighbours
+//    in list order, admission rule :517-531) out of that table, with no memory latency inside the loop.  The replay
+//    stops at the first candidate whose list is not in the table (an admission moved a new node to the front) and
+//    the next round fetches again.  Scoring a row the serial algorithm would never have scored has no effect.
+//
+//  * `nearest` is a sorted array across the registers of wave 0 (4 registers x 64 lanes, ef <= 256) and `candidates`
+//    is implicit (the unexpanded members of `nearest`): identical to the reference's two BinaryHeaps while all
+//    distances inside them are distinct (the argument is in kernels_graph_fast.h).  Every admission checks for an
+//    equal distance already present; at the first one the layer's search starts again with the reference's heaps
+//    restated in LDS (lds_push_parallel / lds_pop_parallel, kernels_graph.h), so ties resolve as in the reference.
+//
+//  * prune_neighbors_with_new_node recomputes the distances from the neighbour to its (<= M + 1) list members.
+//    Those are the same pure function: the distance of every stored edge is kept beside the adjacency row
+//    (dist0 / distU, written when the edge is made; graph_edge_dist_kernel fills them for graphs that were uploaded),
+//    and d(base, new) is the new node's own search result — (a-b)^2 == (b-a)^2 bit for bit — so the prune is a stable
+//    rank of numbers already on hand and scores nothing.
+//
+//  * Several inserts are speculated at once (hnsw_insert_search_kernel: one workgroup per insert, all against the
+//    same frozen graph) and committed in order by ONE workgroup (hnsw_insert_commit_kernel).  A speculated search is
+//    used only if none of the adjacency rows it expanded was changed by an earlier insert of the same batch (each row
+//    carries the tag of the batch that last changed it) and the entry point is the same; otherwise the commit kernel
+//    searches again on the spot, or stops so that the rest of the batch is speculated again.
+#pragma once
+#include "kernels_graph_fast.h"
+
+#pragma clang fp contract(off)
+
+namespace fvdb {
+
+constexpr int kBuildWaves = 8;                   // wavefronts per workgroup
+constexpr int kBuildThreads = kBuildWaves * 64;
+constexpr int kSpec = 16;                        // candidates whose lists are wanted on chip each round
+constexpr int kSlots = 32;                       // scored adjacency lists the table holds (>= 2 kSpec)
+constexpr int kBuildLayers = 16;                 // layers of one node handled on chip (level <= 15: p = 0.408^16 otherwise)
+constexpr int kNearRegs = 4;                     // sorted `nearest`: 4 registers x 64 lanes => ef <= 256
+constexpr uint32_t kResWords = 2 + 2 * 64;       // per layer: count, pad, 64 nodes, 64 distances
+constexpr uint32_t kSpecWords = 8 + kBuildLayers * kResWords;  // one speculated insert in HBM
+constexpr uint32_t kLogCap = 2048;               // expanded rows remembered per speculated insert
+constexpr uint32_t kTileRows = 16;               // rows of a wave's product tile
+
+// device-resident state of a graph under construction (one 64-byte record)
+struct BuildState {
+  uint32_t has_entry, entry, entry_level, n_linked;  // n_linked: nodes whose insert has completed
+  uint32_t cursor;                                   // next node of the current fvdb_graph_insert_linked call
+  uint32_t status;                                   // 0 ok; 1: node `cursor` needs the host path (on-chip heap overflow)
+  uint32_t n_valid, n_rerun, n_stopped;              // speculation statistics
+  uint32_t rounds, consumed, scored, ties;           // search statistics (sums)
+  uint32_t pad[3];
+};
+
+struct BuildView {
+  const float* rows;  // [n][dpad]
+  uint32_t dpad;
+  const uint32_t* level;
+  const uint32_t* deleted;
+  uint32_t any_deleted;
+  const uint32_t* ubase;
+  uint32_t* adj0;
+  float* dist0;  // distance of every layer-0 edge, same indexing as adj0 (word 0 of a row unused)
+  uint32_t* adjU;
+  float* distU;
+  uint32_t stride0, strideU;
+  uint32_t* stamp0;  // [n]  tag of the batch that last changed the node's layer-0 row
+  uint32_t* stampU;  // [upper rows]
+  uint32_t M, M0, ef;
+  uint32_t bitmap_words;  // visited bitmap (LDS) words: covers every node index of the graph
+  uint32_t cand_cap;      // restated `candidates` heap slots in LDS
+  BuildState* state;
+  unsigned long long* dbg;  // diagnostic builds (-DFVDB_BUILD_STAMPS): phase times in 10 ns ticks, see fvdb_graph.cpp
+};
+
+// LDS carve-up (byte offsets, 16-byte aligned)
+struct BuildLds {
+  uint32_t bitmap, cand, near, res, nbr, dist, misc, slist, tiles, total;
+};
+__host__ __device__ inline BuildLds build_lds_layout(uint32_t bitmap_words, uint32_t ef, uint32_t cand_cap) {
+  const uint32_t tile_rows = kTileRows;
+  BuildLds L;
+  uint32_t o = 0;
+  auto take = [&](uint32_t bytes) {
+    const uint32_t at = o;
+    o += (bytes + 15u) & ~15u;
+    return at;
+  };
+  L.bitmap = take(bitmap_words * 4);
+  L.cand = take(cand_cap * 8);
+  L.near = take((ef + 2) * 8);
+  L.res = take(kBuildLayers * kResWords * 4);
+  L.nbr = take(kSlots * 64 * 4);
+  L.dist = take(kSlots * 64 * 4);
+  L.misc = take((64 + 2 * kSpec + kSlots) * 4);  // 64 control words, fetch list (nodes, slots), list counts
+  L.slist = take(kSpec * 64 * 2);
+  L.tiles = take(kBuildWaves * tile_rows * kFastStride * 4);
+  L.total = o;
+  return L;
+}
+
+#ifdef FVDB_BUILD_STAMPS
+#define BSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#define BSTAMP_ADD(g, slot, a, b)                                   \
+  do {                                                              \
+    if (threadIdx.x == 0 && (g).dbg) atomicAdd((g).dbg + (slot), (b) - (a)); \
+  } while (0)
+#else
+#define BSTAMP(var)
+#define BSTAMP_ADD(g, slot, a, b)
+#endif
+
+// misc words
+enum { MS_NSPEC = 0, MS_NSCORE = 1, MS_DONE = 2, MS_TIE = 3, MS_OVER = 4, MS_CUR = 5, MS_CURD = 6, MS_CONFLICT = 7,
+       MS_NLOG = 8, MS_NC = 9, MS_NN = 10, MS_FNODE = 64, MS_FSLOT = 64 + kSpec, MS_CNT = 64 + 2 * kSpec };
+
+// ---------------------------------------------------------------------------------------------
+// scoring: RC rows by one wave, one product tile (see score_fixed, kernels_graph_fast.h, for the derivation)
+// ---------------------------------------------------------------------------------------------
+template <int NB, int RC, bool FULL>
+__device__ __forceinline__ float score_tile1(const float* __restrict__ rows, uint32_t dpad, const float2 (&q2)[NB], uint32_t pn,
+                                             uint32_t cnt, float* tile, int lane) {
+  float2 x[RC][NB];
+  const uint32_t last = cnt - 1;
+#pragma unroll
+  for (int r = 0; r < RC; ++r) {
+    const uint32_t rr = (uint32_t)r < last ? (uint32_t)r : last;  // wave-uniform
+    const uint32_t node = __builtin_amdgcn_readlane(pn, rr);
+    const float* row = rows + (size_t)node * dpad;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      const uint32_t j = (uint32_t)c * 128u + 2u * (uint32_t)lane;
+      if (FULL) x[r][c] = *(const float2*)(row + j);
+      else x[r][c] = j < dpad ? *(const float2*)(row + j) : make_float2(0.0f, 0.0f);
+    }
+  }
+  const uint32_t lrow = (uint32_t)lane < (uint32_t)RC ? (uint32_t)lane : (uint32_t)(RC - 1);
+  float acc = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+#pragma unroll
+    for (int r = 0; r < RC; ++r) {
+      const float t0 = q2[c].x - x[r][c].x, t1 = q2[c].y - x[r][c].y;
+      *(float2*)(tile + (uint32_t)r * kFastStride + 2u * (uint32_t)lane) = make_float2(t0 * t0, t1 * t1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float4* p = (const float4*)(tile + lrow * kFastStride);
+#pragma unroll 16
+    for (int i = 0; i < 32; ++i) {
+      const float4 v = p[i];
+      acc = acc + v.x;
+      acc = acc + v.y;
+      acc = acc + v.z;
+      acc = acc + v.w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  return sqrtf(acc);
+}
+
+// rows one wave scores per pass: 16 x NB float2 registers of row data (8 rows beyond 512 dims)
+template <int NB>
+struct BuildRows {
+  static constexpr uint32_t kMax = NB <= 4 ? 16u : 8u;
+};
+
+// `cnt` (1..BuildRows<NB>::kMax) rows, the smallest straight-line form that holds them
+template <int NB, bool FULL>
+__device__ __forceinline__ float score_upto16(const float* __restrict__ rows, uint32_t dpad, const float2 (&q2)[NB], uint32_t pn,
+                                              uint32_t cnt, float* tile, int lane) {
+  if (NB <= 4 && cnt > 8) return score_tile1<NB, (NB <= 4 ? 16 : 8), FULL>(rows, dpad, q2, pn, cnt, tile, lane);
+  if (cnt > 4) return score_tile1<NB, 8, FULL>(rows, dpad, q2, pn, cnt, tile, lane);
+  return score_tile1<NB, 4, FULL>(rows, dpad, q2, pn, cnt, tile, lane);
+}
+
+// wave-wide max / min of a float, result in every lane (DPP row shifts + row broadcasts, no LDS)
+__device__ __forceinline__ float wave_max_f(float v) {
+  const int ninf = (int)0xFF800000u;
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x111, 0xf, 0xf, false)));  // row_shr:1
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x112, 0xf, 0xf, false)));  // row_shr:2
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x114, 0xf, 0xf, false)));  // row_shr:4
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x118, 0xf, 0xf, false)));  // row_shr:8
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x142, 0xa, 0xf, false)));  // row_bcast:15
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x143, 0xc, 0xf, false)));  // row_bcast:31
+  return rlane_f(v, 63);
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+  const int pinf = (int)0x7F800000u;
+  v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(pinf, __float_as_int(v), 0x111, 0xf, 0xf, false)));
+  v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(pinf, __float_as_int(v), 0x112, 0xf, 0xf, false)));
+  v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(pinf, __float_as_int(v), 0x114, 0xf, 0xf, false)));
+  v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(pinf, __float_as_int(v), 0x118, 0xf, 0xf, false)));
+  v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(pinf, __float_as_int(v), 0x142, 0xa, 0xf, false)));
+  v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(pinf, __float_as_int(v), 0x143, 0xc, 0xf, false)));
+  return rlane_f(v, 63);
+}
+
+// lane `l` of `old` <- `value` (both wave-uniform).  The wait states a VALU-written SGPR needs before it selects a lane
+// are spelled out: hipcc does not insert them around an asm statement.
+__device__ __forceinline__ uint32_t writelane_u(uint32_t value, uint32_t l, uint32_t old) {
+  const uint32_t sv = __builtin_amdgcn_readfirstlane(value), sl = __builtin_amdgcn_readfirstlane(l);
+  // gfx9 allows one SGPR operand per VALU instruction: the lane select travels in M0
+  asm volatile("s_nop 3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0\n\ts_nop 1" : "+v"(old) : "s"(sv), "s"(sl) : "m0");
+  return old;
+}
+
+// the same on unsigned values (zero fill: max's identity; min = ~max(~v))
+__device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u(uint32_t v) { return ~wave_max_u(~v); }
+
+// ---------------------------------------------------------------------------------------------
+// per-workgroup context
+// ---------------------------------------------------------------------------------------------
+struct BuildCtx {
+  uint32_t* bitmap;
+  HItem* cand;
+  HItem* near;
+  uint32_t* res;    // [kBuildLayers][kResWords]
+  uint32_t* nbr;    // [kSlots][64]  neighbour | deleted << 31
+  float* dist;      // [kSlots][64]
+  uint32_t* misc;
+  uint16_t* slist;  // rows to score this round: list * 64 + position
+  float* tile;      // this wave's product tile
+  int lane, wave;
+};
+
+__device__ __forceinline__ BuildCtx build_ctx(unsigned char* lds, const BuildLds& L) {
+  const uint32_t tile_rows = kTileRows;
+  BuildCtx c;
+  c.lane = threadIdx.x & 63;
+  c.wave = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // in a scalar register: `wave == 0` branches are scalar
+  c.bitmap = (uint32_t*)(lds + L.bitmap);
+  c.cand = (HItem*)(lds + L.cand);
+  c.near = (HItem*)(lds + L.near);
+  c.res = (uint32_t*)(lds + L.res);
+  c.nbr = (uint32_t*)(lds + L.nbr);
+  c.dist = (float*)(lds + L.dist);
+  c.misc = (uint32_t*)(lds + L.misc);
+  c.slist = (uint16_t*)(lds + L.slist);
+  c.tile = (float*)(lds + L.tiles) + (size_t)c.wave * tile_rows * kFastStride;
+  return c;
+}
+
+__device__ __forceinline__ const uint32_t* adj_row(const BuildView& g, uint32_t node, uint32_t layer) {
+  return layer == 0 ? g.adj0 + (size_t)node * g.stride0 : g.adjU + (size_t)(g.ubase[node] + layer - 1) * g.strideU;
+}
+
+__device__ __forceinline__ void clear_bitmap(const BuildView& g, BuildCtx& c) {
+  uint4* b4 = (uint4*)c.bitmap;
+  const uint32_t n4 = (g.bitmap_words + 3) >> 2;  // the carve is padded to 16 bytes
+  for (uint32_t i = threadIdx.x; i < n4; i += kBuildThreads) b4[i] = make_uint4(0, 0, 0, 0);
+}
+
+// Fetch the adjacency rows of the round's new candidates — misc[MS_FNODE + i] into table slot misc[MS_FSLOT + i],
+// i < nf — drop what is visited already, list the rest for scoring.  Wave w takes entries w, w + 8, ...
+// A candidate below the layer is not expanded (:503).
+__device__ __forceinline__ void fetch_lists(const BuildView& g, BuildCtx& c, uint32_t nf, uint32_t layer) {
+  const int lane = c.lane;
+  for (uint32_t i = c.wave; i < nf; i += kBuildWaves) {
+    const uint32_t node = c.misc[MS_FNODE + i], p = c.misc[MS_FSLOT + i];
+    uint32_t cnt = 0, nb = 0;
+    if (layer == 0 || g.level[node] >= layer) {
+      const uint32_t* row = adj_row(g, node, layer);
+      cnt = __builtin_amdgcn_readfirstlane(row[0]);
+      if ((uint32_t)lane < cnt) nb = row[1 + lane];
+    }
+    bool fresh = false;
+    if ((uint32_t)lane < cnt) {
+      fresh = ((c.bitmap[nb >> 5] >> (nb & 31)) & 1u) == 0;
+      if (g.any_deleted && g.deleted[nb]) {
+        nb |= 0x80000000u;  // visited like any other neighbour, never scored (:511-513)
+        fresh = false;
+      }
+      c.nbr[p * 64 + lane] = nb;
+    }
+    const uint64_t fm = __ballot(fresh);
+    const uint32_t nfresh = __popcll(fm);
+    uint32_t base = 0;
+    if (lane == 0) {
+      c.misc[MS_CNT + p] = cnt;
+      if (nfresh) base = atomicAdd(&c.misc[MS_NSCORE], nfresh);
+    }
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (fresh) c.slist[base + __popcll(fm & ((1ull << lane) - 1))] = (uint16_t)(p * 64 + lane);
+  }
+}
+
+// Score the listed rows on all waves; distances land in dist[slot][position].
+template <int NB, bool FULL>
+__device__ __forceinline__ void score_lists(const BuildView& g, BuildCtx& c, const float2 (&q2)[NB], uint32_t U) {
+  if (U == 0) return;
+  const uint32_t per = (U + kBuildWaves - 1) / kBuildWaves;
+  const uint32_t rc = per <= 4 ? 4u : (per <= 8 ? 8u : BuildRows<NB>::kMax);
+  for (uint32_t base = (uint32_t)c.wave * rc; base < U; base += kBuildWaves * rc) {
+    const uint32_t cnt = min(rc, U - base);
+    const uint32_t code = (uint32_t)c.lane < cnt ? (uint32_t)c.slist[base + c.lane] : 0u;
+    const uint32_t pn = (uint32_t)c.lane < cnt ? (c.nbr[code] & 0x7FFFFFFFu) : 0u;
+    const float d = score_upto16<NB, FULL>(g.rows, g.dpad, q2, pn, cnt, c.tile, c.lane);
+    if ((uint32_t)c.lane < cnt) c.dist[code] = d;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// search_layer with ef = 1 (:284-290): with one slot in `nearest` every admission is a new minimum, the next pop
+// returns it, and the loop ends at the first hop that admits nobody — a greedy walk.  In a hop the neighbours are
+// tested in list order against the running minimum with `<`, so the hop's winner is the FIRST neighbour holding the
+// smallest distance below the current one.  Returns (node, distance) in every thread.
+// ---------------------------------------------------------------------------------------------
+template <int NB, bool FULL>
+__device__ __forceinline__ void greedy_layer(const BuildView& g, BuildCtx& c, const float2 (&q2)[NB], uint32_t layer, uint32_t& cur,
+                                             float& cur_d, uint32_t* elog) {
+  clear_bitmap(g, c);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicOr(&c.bitmap[cur >> 5], 1u << (cur & 31));
+    c.misc[MS_FNODE] = cur;
+    c.misc[MS_FSLOT] = 0;
+    c.misc[MS_NSCORE] = 0;
+  }
+  __syncthreads();
+  for (;;) {
+    fetch_lists(g, c, 1, layer);
+    __syncthreads();
+    const uint32_t U = c.misc[MS_NSCORE];
+    score_lists<NB, FULL>(g, c, q2, U);
+    __syncthreads();
+    if (c.wave == 0) {
+      const int lane = c.lane;
+      const uint32_t cnt = c.misc[MS_CNT];
+      uint32_t nb = 0;
+      bool keep = false;
+      float d = __uint_as_float(0x7F800000u);
+      if ((uint32_t)lane < cnt) {
+        nb = c.nbr[lane];
+        const uint32_t id = nb & 0x7FFFFFFFu;
+        const uint32_t bit = 1u << (id & 31);
+        const bool fresh = (c.bitmap[id >> 5] & bit) == 0;
+        if (fresh) atomicOr(&c.bitmap[id >> 5], bit);  // visited.insert (:506-507)
+        keep = fresh && (nb >> 31) == 0;
+        if (keep) d = c.dist[lane];
+      }
+      // first lane holding the minimum
+      const float m = wave_min_f(d);
+      const uint64_t at = __ballot(keep && d == m);
+      uint32_t nxt = cur;
+      float nd = cur_d;
+      uint32_t moved = 0;
+      if (at && m < cur_d) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(at);
+        nxt = __builtin_amdgcn_readlane(nb, l);
+        nd = m;
+        moved = 1;
+      }
+      if (lane == 0) {
+        if (elog) {
+          const uint32_t nl = c.misc[MS_NLOG];
+          if (nl < kLogCap) elog[nl] = layer == 0 ? cur : (0x80000000u | (g.ubase[cur] + layer - 1));
+          c.misc[MS_NLOG] = nl + 1;
+        }
+        c.misc[MS_CUR] = nxt;
+        c.misc[MS_CURD] = __float_as_uint(nd);
+        c.misc[MS_DONE] = moved ? 0u : 1u;
+        c.misc[MS_FNODE] = nxt;
+        c.misc[MS_NSCORE] = 0;
+      }
+    }
+    __syncthreads();
+    cur = c.misc[MS_CUR];
+    cur_d = __uint_as_float(c.misc[MS_CURD]);
+    const uint32_t done = c.misc[MS_DONE];
+    __syncthreads();
+    if (done) break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// `nearest` as a SET across kNearRegs registers of wave 0: slot s lives in register s / 64, lane s % 64, slots fill in
+// admission order and an admission into the full set overwrites the slot of the maximum.  With distinct distances
+// (checked at every admission) a priority queue is a function of its contents, so the set with a running maximum
+// (`worst`) and a minimum-of-the-unexpanded reduction (the pop of `candidates`) behaves as the reference's two heaps.
+// Distances are kept as their bit patterns: for values >= +0 unsigned order is float order.  A free slot holds
+// (0xFFFFFFFF, +inf): "expanded" for the minimum search, equal to no finite distance.
+// ---------------------------------------------------------------------------------------------
+struct NearSet {
+  uint32_t n[kNearRegs];  // node | expanded << 31
+  uint32_t d[kNearRegs];  // distance bits
+};
+
+// write (node, distance bits) into slot `at` (all three wave-uniform)
+__device__ __forceinline__ void near_write(NearSet& h, uint32_t at, uint32_t node, uint32_t dbits) {
+  const uint32_t l = at & 63;
+#pragma unroll
+  for (int r = 0; r < kNearRegs; ++r)
+    if ((at >> 6) == (uint32_t)r) {
+      h.n[r] = writelane_u(node, l, h.n[r]);
+      h.d[r] = writelane_u(dbits, l, h.d[r]);
+    }
+}
+
+// maximum of register r over the slots below ef, and the lane that holds it
+__device__ __forceinline__ void near_reg_max(const NearSet& h, int r, uint32_t ef, int lane, uint32_t& m, uint32_t& ml) {
+  const bool in = (uint32_t)(r * 64 + lane) < ef;
+  const uint32_t v = in ? h.d[r] : 0u;
+  m = wave_max_u(v);
+  const uint64_t at = __ballot(in && v == m);
+  ml = at ? (uint32_t)__builtin_ctzll(at) : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// search_layer(query, start, ef, layer) (:469-554), whole workgroup.  Result: the first min(64, |nearest|) members in
+// ascending order -> res[layer] (count, nodes, distances).
+// EXACT = false: `nearest` as a register set; returns false (nothing written) when two members met with equal distances.
+// EXACT = true : the reference's heaps restated in LDS; returns false when `candidates` outgrew its LDS slots.
+//
+// Rounds.  A table of kSlots scored adjacency lists lives in LDS (slot -> node in a register of wave 0).  Wave 0
+// replays the reference's loop out of the table until the next candidate's list is missing; it then names the kSpec
+// nearest unexpanded candidates, the ones not in the table yet are fetched and scored by all waves, and the replay
+// goes on.  A list is fetched once: it stays in the table until its candidate is expanded or falls out of the kSpec
+// nearest.
+// ---------------------------------------------------------------------------------------------
+template <int NB, bool FULL, bool EXACT>
+__device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c, const float2 (&q2)[NB], uint32_t layer, uint32_t start,
+                                                float start_d, uint32_t* elog, uint32_t* stat) {
+  const int lane = c.lane;
+  const uint32_t ef = g.ef;
+  clear_bitmap(g, c);
+  __syncthreads();
+  NearSet h;
+#pragma unroll
+  for (int r = 0; r < kNearRegs; ++r) {
+    h.n[r] = 0xFFFFFFFFu;
+    h.d[r] = 0x7F800000u;
+  }
+  uint32_t nN = 0, nC = 0;          // wave 0's copies are the live ones
+  uint32_t slot_node = 0xFFFFFFFFu;  // wave 0, lane l < kSlots: the node whose list table slot l holds
+  // non-EXACT: the maximum of the set.  While it fills: a running maximum.  Once full: per-register maxima (rm, lane
+  // rl), the set's maximum is the largest of them (register wr) — an admission then re-reduces ONE register.
+  uint32_t worst = 0, wr = 0;
+  uint32_t rm[kNearRegs], rl[kNearRegs];
+#pragma unroll
+  for (int r = 0; r < kNearRegs; ++r) rm[r] = rl[r] = 0;
+  auto pick_worst = [&]() {
+    worst = rm[0];
+    wr = 0;
+#pragma unroll
+    for (int r = 1; r < kNearRegs; ++r)
+      if (rm[r] > worst) {
+        worst = rm[r];
+        wr = (uint32_t)r;
+      }
+  };
+  if (c.wave == 0) {
+    if (lane == 0) {
+      atomicOr(&c.bitmap[start >> 5], 1u << (start & 31));
+      c.misc[MS_NSCORE] = 0;
+      c.misc[MS_TIE] = 0;
+      c.misc[MS_OVER] = 0;
+    }
+    if (EXACT) {
+      lds_push_parallel(c.cand, nC, HItem{start, start_d}, lane);
+      lds_push_parallel(c.near, nN, HItem{start, -start_d}, lane);
+    } else {
+      near_write(h, 0, start, __float_as_uint(start_d));
+      nN = 1;
+      worst = __float_as_uint(start_d);
+      if (ef == 1) {
+        rm[0] = worst;
+        rl[0] = 0;
+      }
+    }
+  }
+  uint32_t rounds = 0, consumed = 0, scored = 0;
+  for (;;) {
+    BSTAMP(t0);
+    if (c.wave == 0) {
+      bool tie = false, over = false, finished = false;
+      // ---- the reference's loop, out of the table ----
+      for (;;) {
+        uint32_t node, slot = 0;
+        if (EXACT) {
+          if (nC == 0) {
+            finished = true;
+            break;
+          }
+          const HItem top = c.cand[0];
+          if (top.d > -c.near[0].d) {  // :499-501
+            finished = true;
+            break;
+          }
+          node = top.node;
+        } else {
+          // candidates.pop(): the nearest member not yet expanded; none left = the reference's exits (:498-501)
+          uint32_t key[kNearRegs], m = 0xFFFFFFFFu;
+#pragma unroll
+          for (int r = 0; r < kNearRegs; ++r) {
+            key[r] = (h.n[r] >> 31) ? 0xFFFFFFFFu : h.d[r];
+            m = min(m, key[r]);
+          }
+          const uint32_t mv = wave_min_u(m);
+          if (mv == 0xFFFFFFFFu) {
+            finished = true;
+            break;
+          }
+          node = 0;
+#pragma unroll
+          for (int r = kNearRegs - 1; r >= 0; --r) {
+            const uint64_t at = __ballot(key[r] == mv);
+            if (at) {
+              slot = (uint32_t)r * 64u + (uint32_t)__builtin_ctzll(at);
+              node = __builtin_amdgcn_readlane(h.n[r], slot & 63);
+            }
+          }
+        }
+        const uint64_t hit = __ballot(slot_node == node);
+        if (hit == 0) break;  // its list is not on chip: fetch
+        const uint32_t p = (uint32_t)__builtin_ctzll(hit);
+        slot_node = writelane_u(0xFFFFFFFFu, p, slot_node);  // the slot is free again
+        if (EXACT) {
+          (void)lds_pop_parallel(c.cand, nC, lane);
+        } else {
+#pragma unroll
+          for (int r = 0; r < kNearRegs; ++r)
+            if ((slot >> 6) == (uint32_t)r) h.n[r] = writelane_u(node | 0x80000000u, slot & 63, h.n[r]);
+        }
+        consumed += 1;
+        if (elog && lane == 0) {
+          const uint32_t nl = c.misc[MS_NLOG];
+          if (nl < kLogCap) elog[nl] = layer == 0 ? node : (0x80000000u | (g.ubase[node] + layer - 1));
+          c.misc[MS_NLOG] = nl + 1;
+        }
+        const uint32_t cnt = c.misc[MS_CNT + p];
+        uint32_t nb = 0;
+        bool keep = false;
+        uint32_t db = 0x7F800000u;
+        if ((uint32_t)lane < cnt) {
+          nb = c.nbr[p * 64 + lane];
+          const uint32_t id = nb & 0x7FFFFFFFu;
+          const uint32_t bit = 1u << (id & 31);
+          const bool fresh = (c.bitmap[id >> 5] & bit) == 0;
+          if (fresh) atomicOr(&c.bitmap[id >> 5], bit);  // visited.insert (:506-507)
+          keep = fresh && (nb >> 31) == 0;                // deleted: visited, skipped (:511-513)
+          if (keep) db = __float_as_uint(c.dist[p * 64 + lane]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // admission (:517-531) in list order; `worst` only shrinks while they are applied
+        if (EXACT) worst = __float_as_uint(-c.near[0].d);
+        uint64_t todo = __ballot(keep && (nN < ef || db < worst));
+        while (todo) {
+          const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+          todo &= todo - 1;
+          const uint32_t di = __builtin_amdgcn_readlane(db, i);
+          if (!(nN < ef || di < worst)) continue;
+          const uint32_t ni = __builtin_amdgcn_readlane(nb, i);
+#ifdef FVDB_BUILD_STAMPS
+          if (threadIdx.x == 0 && g.dbg) atomicAdd(g.dbg + 8, 1ull);
+#endif
+          if (EXACT) {
+            if (nC >= g.cand_cap) {
+              over = true;
+              break;
+            }
+            const float df = __uint_as_float(di);
+            lds_push_parallel(c.cand, nC, HItem{ni, df}, lane);
+            lds_push_parallel(c.near, nN, HItem{ni, -df}, lane);
+            if (nN > ef) (void)lds_pop_parallel(c.near, nN, lane);
+            worst = __float_as_uint(-c.near[0].d);
+          } else {
+            bool eq = false;
+#pragma unroll
+            for (int r = 0; r < kNearRegs; ++r) eq = eq || h.d[r] == di;
+            if (__ballot(eq)) {  // equal distances inside the heaps: their order is the reference's heap layout
+              tie = true;
+              break;
+            }
+            if (nN < ef) {
+              near_write(h, nN, ni, di);
+              nN += 1;
+              worst = max(worst, di);
+              if (nN == ef) {  // full from here on: per-register maxima
+#pragma unroll
+                for (int r = 0; r < kNearRegs; ++r) near_reg_max(h, r, ef, lane, rm[r], rl[r]);
+                pick_worst();
+              }
+            } else {  // the maximum leaves (nearest.pop(), :528-530), the newcomer takes its slot
+              near_write(h, wr * 64u + rl[wr], ni, di);
+#pragma unroll
+              for (int r = 0; r < kNearRegs; ++r)
+                if (wr == (uint32_t)r) near_reg_max(h, r, ef, lane, rm[r], rl[r]);
+              pick_worst();
+            }
+          }
+        }
+        if (tie || over) break;
+      }
+      BSTAMP(ta);
+      BSTAMP_ADD(g, 6, t0, ta);
+      // ---- the kSpec nearest unexpanded candidates; those without a list in the table are fetched ----
+      uint32_t nf = 0;
+      if (!tie && !over && !finished) {
+        uint32_t spec_l = 0xFFFFFFFFu;  // lane i < ns: the i-th named candidate
+        uint32_t ns = 0;
+        if (EXACT) {
+          // the front of the heap array: its root is the next pop for certain, the levels below it are likely followers
+          const float w = -c.near[0].d;
+          const uint32_t lim = min((uint32_t)kSpec, nC);
+          HItem it = HItem{0, 0.0f};
+          if ((uint32_t)lane < lim) it = c.cand[lane];
+          const bool ok = (uint32_t)lane < lim && !(it.d > w);
+          uint64_t om = __ballot(ok);
+          while (om) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(om);
+            om &= om - 1;
+            spec_l = writelane_u(__builtin_amdgcn_readlane(it.node, l), ns, spec_l);
+            ns += 1;
+          }
+        } else {
+          // all unexpanded members with distance <= t, t = the largest threshold (bisection on the bit pattern) that
+          // names at most kSpec of them; the minimum is always among them
+          uint32_t key[kNearRegs], m = 0xFFFFFFFFu;
+#pragma unroll
+          for (int r = 0; r < kNearRegs; ++r) {
+            key[r] = (h.n[r] >> 31) ? 0xFFFFFFFFu : h.d[r];
+            m = min(m, key[r]);
+          }
+          auto count_le = [&](uint32_t t) {
+            uint32_t cn = 0;
+#pragma unroll
+            for (int r = 0; r < kNearRegs; ++r) cn += __popcll(__ballot(key[r] <= t));
+            return cn;
+          };
+          uint32_t lo = wave_min_u(m), hi = worst;
+          uint32_t t = hi;
+          if (count_le(hi) > (uint32_t)kSpec) {
+            for (int it = 0; it < 14 && hi - lo > 1; ++it) {
+              const uint32_t mid = lo + ((hi - lo) >> 1);
+              const uint32_t cn = count_le(mid);
+              if (cn <= (uint32_t)kSpec) lo = mid;
+              else hi = mid;
+              if (cn == (uint32_t)kSpec) break;
+            }
+            t = lo;
+          }
+#pragma unroll
+          for (int r = 0; r < kNearRegs; ++r) {
+            uint64_t om = __ballot(key[r] <= t);
+            while (om && ns < (uint32_t)kSpec) {
+              const uint32_t l = (uint32_t)__builtin_ctzll(om);
+              om &= om - 1;
+              spec_l = writelane_u(__builtin_amdgcn_readlane(h.n[r], l), ns, spec_l);
+              ns += 1;
+            }
+          }
+        }
+        BSTAMP(tb);
+        BSTAMP_ADD(g, 7, ta, tb);
+        // table slots: keep the lists of named candidates, hand the other slots to the named ones without a list
+        uint64_t in_s = 0, miss = 0;
+        for (uint32_t i = 0; i < ns; ++i) {
+          const uint32_t sv = __builtin_amdgcn_readlane(spec_l, i);
+          const uint64_t at = __ballot(slot_node == sv);
+          if (at) in_s |= at;
+          else miss |= 1ull << i;
+        }
+        uint64_t free_s = ~in_s & ((1ull << kSlots) - 1);
+        while (miss) {
+          const uint32_t i = (uint32_t)__builtin_ctzll(miss);
+          miss &= miss - 1;
+          const uint32_t sl = (uint32_t)__builtin_ctzll(free_s);  // kSlots >= 2 kSpec: never exhausted
+          free_s &= free_s - 1;
+          const uint32_t sv = __builtin_amdgcn_readlane(spec_l, i);
+          slot_node = writelane_u(sv, sl, slot_node);
+          if (lane == 0) {
+            c.misc[MS_FNODE + nf] = sv;
+            c.misc[MS_FSLOT + nf] = sl;
+          }
+          nf += 1;
+        }
+      }
+      if (lane == 0) {
+        c.misc[MS_NSPEC] = nf;
+        c.misc[MS_NSCORE] = 0;
+        if (tie) c.misc[MS_TIE] = 1;
+        if (over) c.misc[MS_OVER] = 1;
+      }
+    }
+    BSTAMP(t1);
+    __syncthreads();
+    const uint32_t nf = c.misc[MS_NSPEC];
+    if (nf == 0) break;  // search finished, or a tie / overflow was met
+    fetch_lists(g, c, nf, layer);
+    __syncthreads();
+    BSTAMP(t2);
+    const uint32_t U = c.misc[MS_NSCORE];
+    score_lists<NB, FULL>(g, c, q2, U);
+    __syncthreads();
+    BSTAMP(t3);
+    BSTAMP_ADD(g, 0, t0, t1);
+    BSTAMP_ADD(g, 1, t1, t2);
+    BSTAMP_ADD(g, 2, t2, t3);
+    rounds += 1;
+    scored += U;
+  }
+  const bool failed = (c.misc[MS_TIE] | c.misc[MS_OVER]) != 0;
+  __syncthreads();
+  if (threadIdx.x == 0 && stat) {
+    stat[0] += rounds;
+    stat[1] += consumed;
+    stat[2] += scored;
+  }
+  if (failed) return false;
+  // ---- result: `nearest` in heap order, stable-sorted by distance (:541-553); the first 64 are enough ----
+  uint32_t* out = c.res + layer * kResWords;
+  if (c.wave == 0) {
+    if (!EXACT) {  // the set, any order (no two distances are equal), in the heap array's form (negated distances)
+#pragma unroll
+      for (int r = 0; r < kNearRegs; ++r)
+        if ((uint32_t)(r * 64 + lane) < nN) c.near[r * 64 + lane] = HItem{h.n[r] & 0x7FFFFFFFu, -__uint_as_float(h.d[r])};
+    }
+    if (lane == 0) c.misc[MS_NN] = nN;
+  }
+  __syncthreads();
+  const uint32_t nn = c.misc[MS_NN];
+  for (uint32_t i = threadIdx.x; i < nn; i += kBuildThreads) {
+    const HItem me = c.near[i];
+    const float md = -me.d;
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < nn; ++j) {
+      const float dj = -c.near[j].d;
+      rank += (dj < md || (dj == md && j < i)) ? 1u : 0u;
+    }
+    if (rank < 64) {
+      out[2 + rank] = me.node;
+      out[2 + 64 + rank] = __float_as_uint(md);
+    }
+  }
+  if (threadIdx.x == 0) out[0] = min(nn, 64u);
+  __syncthreads();
+  return true;
+}
+
+// search_layer(ef) with the tie rule: sorted registers first, the restated heaps when two members tie.
+// false: the restated `candidates` heap outgrew its LDS slots (host path for this node).
+template <int NB, bool FULL>
+__device__ __forceinline__ bool ef_search(const BuildView& g, BuildCtx& c, const float2 (&q2)[NB], uint32_t layer, uint32_t start,
+                                          float start_d, uint32_t* elog, uint32_t* stat, bool exact_on_tie) {
+  const uint32_t log0 = c.misc[MS_NLOG];
+  if (g.ef <= (uint32_t)kNearRegs * 64u) {
+    if (ef_search_layer<NB, FULL, false>(g, c, q2, layer, start, start_d, elog, stat)) return true;
+    if (!exact_on_tie) return false;  // a speculation far down the batch: not worth twice the time of the others
+    if (threadIdx.x == 0) {
+      c.misc[MS_NLOG] = log0;  // the aborted attempt expanded a prefix of what the exact run expands
+      if (stat) stat[3] += 1;
+    }
+    __syncthreads();
+  }
+  return ef_search_layer<NB, FULL, true>(g, c, q2, layer, start, start_d, elog, stat);
+}
+
+// ---------------------------------------------------------------------------------------------
+// All searches of one insert (:262-305): distance to the entry point, greedy descent from min(level, entry_level) down
+// to layer 0, then search_layer(ef) on layers 0..level, each starting at the descent's final node (or at the entry
+// point above its level).  Linking on layer l touches layer-l rows only, and the search on layer l + 1 reads layer
+// l + 1 rows only, so all of an insert's searches can run before any of its links are made.
+// Results -> res[layer]; false = host path needed.
+// ---------------------------------------------------------------------------------------------
+template <int NB, bool FULL>
+__device__ __forceinline__ bool insert_searches(const BuildView& g, BuildCtx& c, uint32_t node, uint32_t level, uint32_t entry,
+                                                uint32_t entry_level, uint32_t* elog, uint32_t* stat, bool exact_on_tie = true) {
+  float2 q2[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const uint32_t j = (uint32_t)b * 128u + 2u * (uint32_t)c.lane;
+    q2[b] = j < g.dpad ? *(const float2*)(g.rows + (size_t)node * g.dpad + j) : make_float2(0.0f, 0.0f);
+  }
+  if (threadIdx.x == 0) {
+    c.misc[MS_NLOG] = 0;
+    c.misc[MS_NSCORE] = 0;
+  }
+  // d(q, entry) (:277-281)
+  if (c.wave == 0) {
+    const float d0 = score_tile1<NB, 4, FULL>(g.rows, g.dpad, q2, entry, 1, c.tile, c.lane);
+    if (c.lane == 0) c.misc[MS_CURD] = __float_as_uint(d0);
+  }
+  __syncthreads();
+  const float entry_d = __uint_as_float(c.misc[MS_CURD]);
+  __syncthreads();
+  uint32_t cur = entry;
+  float cur_d = entry_d;
+  const uint32_t search_level = min(level, entry_level);
+  BSTAMP(tg0);
+  for (uint32_t lc = search_level + 1; lc-- > 0;) greedy_layer<NB, FULL>(g, c, q2, lc, cur, cur_d, elog);
+  BSTAMP(tg1);
+  BSTAMP_ADD(g, 3, tg0, tg1);
+  for (uint32_t lc = 0; lc <= level; ++lc) {
+    const bool low = lc <= search_level;
+    if (!ef_search<NB, FULL>(g, c, q2, lc, low ? cur : entry, low ? cur_d : entry_d, elog, stat, exact_on_tie)) return false;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Links of one insert (:293-362) from res[]: the new node's rows, the back-links, the prunes.  `tag`: this batch.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void insert_links(const BuildView& g, BuildCtx& c, uint32_t node, uint32_t level, uint32_t tag) {
+  const int lane = c.lane;
+  for (uint32_t lc = 0; lc <= level; ++lc) {
+    const uint32_t* r = c.res + lc * kResWords;
+    const uint32_t m = lc == 0 ? g.M0 : g.M;
+    const uint32_t take = min(r[0], m);  // select_neighbors: the first m (:556-558)
+    const uint32_t stride = lc == 0 ? g.stride0 : g.strideU;
+    const size_t mine = lc == 0 ? (size_t)node * g.stride0 : (size_t)(g.ubase[node] + lc - 1) * g.strideU;
+    uint32_t* adj = lc == 0 ? g.adj0 : g.adjU;
+    float* adjd = lc == 0 ? g.dist0 : g.distU;
+    if (c.wave == 0) {
+      if ((uint32_t)lane < take) {
+        adj[mine + 1 + lane] = r[2 + lane];
+        adjd[mine + 1 + lane] = __uint_as_float(r[2 + 64 + lane]);
+      }
+      if (lane == 0) adj[mine] = take;
+    }
+    for (uint32_t t = c.wave; t < take; t += kBuildWaves) {
+      const uint32_t nbv = r[2 + t];
+      const float dn = __uint_as_float(r[2 + 64 + t]);
+      if (lc > 0 && g.level[nbv] < lc) continue;  // :323 (a start node taken from a lower layer)
+      const size_t at = lc == 0 ? (size_t)nbv * g.stride0 : (size_t)(g.ubase[nbv] + lc - 1) * g.strideU;
+      const uint32_t k = __builtin_amdgcn_readfirstlane(adj[at]);
+      if (k < m && k + 1 < stride) {  // room: append (:324)
+        if (lane == 0) {
+          adj[at + 1 + k] = node;
+          adjd[at + 1 + k] = dn;
+          adj[at] = k + 1;
+          (lc == 0 ? g.stamp0[nbv] : g.stampU[g.ubase[nbv] + lc - 1]) = tag;
+        }
+        continue;
+      }
+      // prune_neighbors_with_new_node (:588-624): the list + the new node, stable sort by distance, keep m
+      const uint32_t tot = k + 1;  // <= 64: the row stride bounds k
+      uint32_t e_n = node;
+      float e_d = dn;
+      if ((uint32_t)lane < k) {
+        e_n = adj[at + 1 + lane];
+        e_d = adjd[at + 1 + lane];
+      }
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < tot; ++j) {
+        const float dj = rlane_f(e_d, j);
+        rank += (dj < e_d || (dj == e_d && j < (uint32_t)lane)) ? 1u : 0u;
+      }
+      const bool in = (uint32_t)lane < tot;
+      const bool same = __ballot(in && (uint32_t)lane < k && rank != (uint32_t)lane) == 0 && k == m;  // old list kept as it was
+      if (!same) {
+        if (in && rank < m) {
+          adj[at + 1 + rank] = e_n;
+          adjd[at + 1 + rank] = e_d;
+        }
+        if (lane == 0) {
+          adj[at] = min(tot, m);
+          (lc == 0 ? g.stamp0[nbv] : g.stampU[g.ubase[nbv] + lc - 1]) = tag;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+// Speculation: workgroup b searches for node first + cursor + b against the graph as it stands.
+template <int NB, bool FULL>
+__global__ __launch_bounds__(kBuildThreads, 1) void hnsw_insert_search_kernel(const BuildView g, uint32_t first, uint32_t n,
+                                                                              uint32_t* __restrict__ spec /* [grid][kSpecWords] */,
+                                                                              uint32_t* __restrict__ elogs /* [grid][kLogCap] */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_b[];
+  const BuildLds L = build_lds_layout(g.bitmap_words, g.ef, g.cand_cap);
+  BuildCtx c = build_ctx(lds_b, L);
+  const BuildState st = *g.state;
+  const uint32_t idx = st.cursor + blockIdx.x;
+  uint32_t* out = spec + (size_t)blockIdx.x * kSpecWords;
+  if (idx >= n || st.status != 0) {
+    if (threadIdx.x == 0) out[0] = 0;  // nothing speculated
+    return;
+  }
+  const uint32_t node = first + idx;
+  const uint32_t level = g.level[node];
+  if (!st.has_entry || level >= (uint32_t)kBuildLayers) {
+    if (threadIdx.x == 0) out[0] = 0;
+    return;
+  }
+  uint32_t* elog = elogs + (size_t)blockIdx.x * kLogCap;
+  // a search that meets equal distances starts again with the restated heaps — twice the time: only the first few
+  // speculations of a batch, the ones most likely to be adopted, do that; the others are left to the next batch
+  const bool ok = insert_searches<NB, FULL>(g, c, node, level, st.entry, st.entry_level, elog, nullptr, blockIdx.x < 4);
+  __syncthreads();
+  // header: [0] 1 = usable, [1] node, [2] entry it started from, [3] expanded rows logged
+  const uint32_t nlog = c.misc[MS_NLOG];
+  if (threadIdx.x == 0) {
+    out[0] = (ok && nlog <= kLogCap) ? 1u : 0u;
+    out[1] = node;
+    out[2] = st.entry;
+    out[3] = nlog;
+  }
+  const uint32_t words = (level + 1) * kResWords;
+  for (uint32_t i = threadIdx.x; i < words; i += kBuildThreads) out[8 + i] = c.res[i];
+}
+
+// Commit: ONE workgroup takes the nodes first + cursor ... in order.  A speculated search is adopted when every row it
+// expanded is untouched by this batch and the entry point is the one it started from; otherwise the search runs here
+// (at most max_rerun times per launch, then the kernel stops and leaves the rest to the next speculation).
+// spec == nullptr: no speculation, every search runs here (small graphs, where every insert touches what the next reads).
+template <int NB, bool FULL>
+__global__ __launch_bounds__(kBuildThreads, 1) void hnsw_insert_commit_kernel(const BuildView g, uint32_t first, uint32_t n, uint32_t count,
+                                                                              uint32_t tag, uint32_t max_rerun,
+                                                                              const uint32_t* __restrict__ spec,
+                                                                              const uint32_t* __restrict__ elogs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_b[];
+  const BuildLds L = build_lds_layout(g.bitmap_words, g.ef, g.cand_cap);
+  BuildCtx c = build_ctx(lds_b, L);
+  BuildState st = *g.state;
+  if (st.status != 0) return;
+  uint32_t reruns = 0;
+  uint32_t stat[4] = {0, 0, 0, 0};
+  uint32_t n_valid = 0, n_rerun = 0, stopped = 0;
+  uint32_t done = 0;
+  for (uint32_t b = 0; b < count; ++b) {
+    const uint32_t idx = st.cursor + b;
+    if (idx >= n) break;
+    const uint32_t node = first + idx;
+    const uint32_t level = g.level[node];
+    if (level >= (uint32_t)kBuildLayers) {
+      st.status = 1;
+      break;
+    }
+    if (!st.has_entry) {  // the first node: entry point, no links (:249-258)
+      if (threadIdx.x == 0) {
+        g.adj0[(size_t)node * g.stride0] = 0;
+        for (uint32_t l = 1; l <= level; ++l) g.adjU[(size_t)(g.ubase[node] + l - 1) * g.strideU] = 0;
+      }
+      st.has_entry = 1;
+      st.entry = node;
+      st.entry_level = level;
+      st.n_linked += 1;
+      done += 1;
+      __syncthreads();
+      continue;
+    }
+    bool have = false;
+    if (spec) {
+      const uint32_t* sp = spec + (size_t)b * kSpecWords;
+      if (sp[0] == 1 && sp[1] == node && sp[2] == st.entry) {
+        if (threadIdx.x == 0) c.misc[MS_CONFLICT] = 0;
+        __syncthreads();
+        const uint32_t nlog = sp[3];
+        const uint32_t* el = elogs + (size_t)b * kLogCap;
+        bool bad = false;
+        for (uint32_t i = threadIdx.x; i < nlog; i += kBuildThreads) {
+          const uint32_t code = el[i];
+          const uint32_t s = (code >> 31) ? g.stampU[code & 0x7FFFFFFFu] : g.stamp0[code];
+          bad = bad || s == tag;
+        }
+        if (bad) c.misc[MS_CONFLICT] = 1;
+        __syncthreads();
+        have = c.misc[MS_CONFLICT] == 0;
+        if (have) {
+          const uint32_t words = (level + 1) * kResWords;
+          for (uint32_t i = threadIdx.x; i < words; i += kBuildThreads) c.res[i] = sp[8 + i];
+        }
+        __syncthreads();
+      }
+    }
+    if (have) {
+      n_valid += 1;
+    } else {
+      if (spec && done > 0 && reruns >= max_rerun) {  // the first node of a launch is always taken: progress
+        stopped = 1;
+        break;
+      }
+      reruns += 1;
+      n_rerun += 1;
+      BSTAMP(ts0);
+      if (!insert_searches<NB, FULL>(g, c, node, level, st.entry, st.entry_level, nullptr, stat)) {
+        st.status = 1;
+        break;
+      }
+      BSTAMP(ts1);
+      BSTAMP_ADD(g, 4, ts0, ts1);
+    }
+    BSTAMP(tl0);
+    insert_links(g, c, node, level, tag);
+    BSTAMP(tl1);
+    BSTAMP_ADD(g, 5, tl0, tl1);
+    st.n_linked += 1;
+    if (level > st.entry_level) {  // :372-375
+      st.entry = node;
+      st.entry_level = level;
+    }
+    done += 1;
+    __threadfence_block();
+    __syncthreads();  // the rows written above are read by the next insert's searches
+  }
+  if (threadIdx.x == 0) {
+    BuildState* o = g.state;
+    o->has_entry = st.has_entry;
+    o->entry = st.entry;
+    o->entry_level = st.entry_level;
+    o->n_linked = st.n_linked;
+    o->cursor = st.cursor + done;
+    o->status = st.status;
+    o->n_valid += n_valid;
+    o->n_rerun += n_rerun;
+    o->n_stopped += stopped;
+    o->rounds += stat[0];
+    o->consumed += stat[1];
+    o->scored += stat[2];
+    o->ties += stat[3];
+  }
+}
+
+// Distance of every stored edge of the listed rows (code: node for layer 0, 0x80000000 | upper row otherwise, with
+// `owner[i]` = the node the upper row belongs to), or of ALL layer-0 rows / upper rows when codes == nullptr: one wave
+// per row, base = the row's node.  Fills dist0 / distU for graphs whose rows came from the host.
+template <int NB, bool FULL>
+__global__ __launch_bounds__(256) void graph_edge_dist_kernel(const BuildView g, const uint32_t* __restrict__ codes,
+                                                             const uint32_t* __restrict__ owner, uint32_t n_rows, uint32_t upper_all) {
+  const uint32_t tile_rows = kTileRows;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_e[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* tile = (float*)lds_e + (size_t)wave * tile_rows * kFastStride;
+  const uint32_t i = blockIdx.x * 4 + wave;
+  if (i >= n_rows) return;
+  uint32_t base_node;
+  size_t at;
+  bool upper;
+  if (codes) {
+    const uint32_t code = codes[i];
+    upper = (code >> 31) != 0;
+    base_node = upper ? owner[i] : code;
+    at = upper ? (size_t)(code & 0x7FFFFFFFu) * g.strideU : (size_t)code * g.stride0;
+  } else {
+    upper = upper_all != 0;
+    base_node = upper ? owner[i] : i;
+    at = upper ? (size_t)i * g.strideU : (size_t)i * g.stride0;
+  }
+  const uint32_t* adj = upper ? g.adjU : g.adj0;
+  float* adjd = upper ? g.distU : g.dist0;
+  const uint32_t k = __builtin_amdgcn_readfirstlane(adj[at]);
+  if (k == 0) return;
+  float2 q2[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const uint32_t j = (uint32_t)b * 128u + 2u * (uint32_t)lane;
+    q2[b] = j < g.dpad ? *(const float2*)(g.rows + (size_t)base_node * g.dpad + j) : make_float2(0.0f, 0.0f);
+  }
+  for (uint32_t o = 0; o < k; o += BuildRows<NB>::kMax) {
+    const uint32_t cnt = min(BuildRows<NB>::kMax, k - o);
+    const uint32_t pn = (uint32_t)lane < cnt ? adj[at + 1 + o + lane] : 0u;
+    const float d = score_upto16<NB, FULL>(g.rows, g.dpad, q2, pn, cnt, tile, lane);
+    if ((uint32_t)lane < cnt) adjd[at + 1 + o + lane] = d;
+  }
+}
+
+}  // namespace fvdb

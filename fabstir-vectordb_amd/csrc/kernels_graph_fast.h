@@ -251,10 +251,9 @@ __global__ __launch_bounds__(256, (R <= 8 ? 4 : (R <= 12 ? 3 : FVDB_FAST_WAVES16
             pf_node = 0xFFFFFFFFu;
           }
         } else {
-          const uint32_t s = g.slot_of[node] + layer;
-          const uint32_t a0 = g.slot_start[s];
-          cnt = g.slot_start[s + 1] - a0;
-          if ((uint32_t)lane < cnt) nb = g.adj[a0 + lane];
+          const uint32_t* row = g.adjU + (size_t)(g.ubase[node] + layer - 1) * g.strideU;
+          cnt = __builtin_amdgcn_readfirstlane(row[0]);
+          if ((uint32_t)lane < cnt) nb = row[lane + 1];
         }
         bool fresh = false, keep = false;
         if ((uint32_t)lane < cnt) {
@@ -269,11 +268,8 @@ __global__ __launch_bounds__(256, (R <= 8 ? 4 : (R <= 12 ? 3 : FVDB_FAST_WAVES16
         }
         const uint64_t fm = __ballot(fresh), km = __ballot(keep);
         const uint32_t nf = __popcll(fm);
-        if (nT + nf > tcap) {
-          status = 1;
-        } else if (fresh) {
-          tch[nT + __popcll(fm & lt)] = nb;
-        }
+        // a log that fills up stops growing: the layer's map is then cleared whole instead of entry by entry
+        if (fresh && nT + nf <= tcap) tch[nT + __popcll(fm & lt)] = nb;
         nT += nf;
         np = __popcll(km);
         if (keep) pending[__popcll(km & lt)] = nb;  // list order preserved

@@ -66,15 +66,15 @@ int fvh_hnsw_insert(void* p, uint64_t id, const float* v, uint32_t d, int64_t le
 // batch_insert (src/hnsw/operations.rs:74-94): sequential loop, keeps going after a failure
 int fvh_hnsw_batch_insert(void* p, const uint64_t* ids, const float* v, uint64_t n, uint32_t d, const int64_t* levels,
                           uint64_t* n_ok, int* first_error) {
-  uint64_t ok = 0;
-  int err = 0;
-  for (uint64_t i = 0; i < n; ++i) {
-    int rc = ((HNSWIndex*)p)->insert(ids[i], v + i * d, d, levels ? levels[i] : -1);
-    if (rc == 0) ++ok; else if (!err) err = rc;
-  }
-  if (n_ok) *n_ok = ok;
-  if (first_error) *first_error = err;
-  return 0;
+  return ((HNSWIndex*)p)->batch_insert(ids, v, n, d, levels, n_ok, first_error);
+}
+void fvh_hnsw_set_device_insert(void* p, int on, int mode) { ((HNSWIndex*)p)->set_device_insert(on != 0, mode); }
+int fvh_hnsw_device_insert(void* p) { return ((HNSWIndex*)p)->device_insert(); }
+void fvh_hnsw_insert_stats(void* p, fvdb_graph_insert_stats* out, uint64_t* host_path_inserts, uint64_t* upload_bytes) {
+  HNSWIndex* h = (HNSWIndex*)p;
+  if (out) *out = h->insert_stats();
+  if (host_path_inserts) *host_path_inserts = h->host_path_inserts();
+  if (upload_bytes) *upload_bytes = h->graph_upload_bytes();
 }
 int fvh_hnsw_search(void* p, const float* q, uint32_t B, uint32_t d, uint32_t k, uint32_t ef, uint64_t* ids,
                     float* dist, uint32_t* counts) {

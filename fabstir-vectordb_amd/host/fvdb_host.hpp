@@ -142,6 +142,22 @@ class HNSWIndex {
   uint32_t dimension() const { return dim_; }
   size_t assign_level();                                                           // :211
   int insert(uint64_t id, const float* v, uint32_t dim, int64_t forced_level);     // :226
+  // batch_insert (src/hnsw/operations.rs:74-94): the reference's sequential loop, keeps going after a failure.
+  // levels[i] < 0 (or levels == nullptr): drawn with assign_level() in order, like the loop would.  The inserts that
+  // pass the reference's checks are linked on the device in one call (fvdb_graph_insert_linked), strictly in order.
+  int batch_insert(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const int64_t* levels, uint64_t* n_ok,
+                   int* first_error);
+  // Where an insert's searches, links and prunes run: true (default) = on the device against the adjacency in HBM
+  // (kernels_graph_build.h); false = the host algorithm with every distance batch scored on the GPU (fvdb_scorer_*).
+  // Same graph either way.  mode: fvdb_graph_insert_linked's (0 choose, 1 one at a time, 2 speculate batches).
+  void set_device_insert(bool on, int mode = 0) {
+    device_insert_ = on;
+    insert_mode_ = mode;
+  }
+  bool device_insert() const { return device_insert_; }
+  const fvdb_graph_insert_stats& insert_stats() const { return insert_stats_; }  // sums since construction
+  uint64_t host_path_inserts() const { return n_host_inserts_; }
+  uint64_t graph_upload_bytes() const { return graph_ ? fvdb_graph_upload_bytes(graph_) : 0; }
   int search(const float* q, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
              uint32_t* counts);                                                    // :398 (batched, lock-step hops)
   int search_dev(const float* q_dev, uint32_t B, uint32_t dim, uint32_t k, uint32_t ef, uint64_t* ids, float* dist,
@@ -160,7 +176,7 @@ class HNSWIndex {
   uint64_t active_count() const;
   uint64_t vacuum();                                                               // operations.rs:176
   int64_t level_of(uint64_t id) const;
-  int64_t neighbors(uint64_t id, uint32_t layer, uint64_t* out, uint64_t cap) const;
+  int64_t neighbors(uint64_t id, uint32_t layer, uint64_t* out, uint64_t cap);
   const float* vector_of(uint64_t id) const;  // host copy (migration, get_vector_by_id)
   bool contains(uint64_t id) const { return index_of_.count(id) > 0; }
   // Extension (not in the reference): build the graph for n vectors at once.  Levels from the PRNG
@@ -171,8 +187,8 @@ class HNSWIndex {
   int restore(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const uint32_t* levels,
               const uint64_t* nbr_offsets, const uint64_t* nbrs, uint64_t entry_id);
   uint64_t graph_slots() const;
-  uint64_t graph_edges() const;
-  void export_graph(uint64_t* ids, uint32_t* levels, uint64_t* nbr_offsets, uint64_t* nbrs) const;
+  uint64_t graph_edges();
+  void export_graph(uint64_t* ids, uint32_t* levels, uint64_t* nbr_offsets, uint64_t* nbrs);
   uint64_t dist_evals() const { return n_dist_; }
   uint64_t hops() const { return n_hops_; }
   void set_threads(int t) { threads_ = t; }
@@ -241,8 +257,27 @@ class HNSWIndex {
                     uint32_t* counts, const std::vector<uint32_t>& failed);
   int search_host_walk(const float* q, bool q_on_device, uint32_t B, uint32_t k, uint32_t ef, uint64_t* ids,
                        float* dist, uint32_t* counts);
+  // The adjacency lists exist twice: nbrs_ (host) and the fixed-stride rows in HBM (graph_).  host_ahead_: nbrs_ holds
+  // changes the device has not seen (restore, bulk build, vacuum, inserts made before the device graph existed) — the
+  // next device use installs the whole graph once.  dev_ahead_: device inserts have linked nodes whose lists nbrs_
+  // does not hold yet — whoever needs nbrs_ (export, neighbours, host walk, vacuum, a host-path insert) pulls them.
+  // A host-path insert made while the two agree patches the rows it changed (fvdb_graph_set_lists): no whole-graph
+  // upload follows an insert or a delete.
   fvdb_graph* graph_ = nullptr;
-  bool graph_dirty_ = true, device_traversal_ = true;
+  bool host_ahead_ = true, dev_ahead_ = false, device_traversal_ = true, device_insert_ = true;
+  int insert_mode_ = 0;
+  fvdb_graph_insert_stats insert_stats_{};
+  uint64_t n_host_inserts_ = 0;
+  int ensure_graph_handle();
+  int ensure_host_graph();
+  bool device_insert_ok() const;
+  int check_insert(uint64_t id, const float* v, uint32_t dim) const;
+  int insert_host(uint64_t id, const float* v, uint32_t dim, int64_t forced_level);
+  // the host algorithm's links for node `row` (bookkeeping and vector already in place); the (node, layer) lists it
+  // changed are appended to `touched`
+  int link_host(uint32_t row, std::vector<std::pair<uint32_t, uint32_t>>* touched);
+  int push_lists(const std::vector<std::pair<uint32_t, uint32_t>>& touched);
+  void finalize_insert(uint32_t row);
   struct DevSlot {  // per in-flight batch: stream (context), device result buffers, pinned host copies
     fvdb_ctx* ctx = nullptr;  // slot 0 borrows ctx_, the others own theirs
     void *d_nodes = nullptr, *d_dist = nullptr, *d_cnt = nullptr, *d_status = nullptr;

@@ -1,7 +1,8 @@
 // hnsw_index.cpp — HNSWIndex mirror (src/hnsw/core.rs, src/hnsw/operations.rs).
-// The graph, heaps and visited sets live here; every distance is scored on the GPU through
-// fvdb_scorer_* (one launch per hop for the whole query batch, candidates and distances
-// travelling through pinned host memory mapped into the GPU).
+// Ids, levels, flags and a copy of the adjacency live here.  Inserts and batch searches normally run whole on the
+// device against the adjacency in HBM (fvdb_graph_insert_linked / fvdb_graph_search_dev*); the host algorithm below —
+// heaps and visited sets here, every distance batch scored on the GPU through fvdb_scorer_* — is the other mode of
+// both (same results), and what takes over for shapes the device kernels do not serve.
 #include <omp.h>
 
 #include <algorithm>
@@ -197,7 +198,8 @@ int64_t HNSWIndex::level_of(uint64_t id) const {
   return it == index_of_.end() ? -1 : (int64_t)level_[it->second];
 }
 
-int64_t HNSWIndex::neighbors(uint64_t id, uint32_t layer, uint64_t* out, uint64_t cap_out) const {
+int64_t HNSWIndex::neighbors(uint64_t id, uint32_t layer, uint64_t* out, uint64_t cap_out) {
+  if (ensure_host_graph()) return -1;
   auto it = index_of_.find(id);
   if (it == index_of_.end() || layer > level_[it->second]) return -1;
   const auto& s = nbrs_[it->second][layer];
@@ -210,7 +212,7 @@ int HNSWIndex::mark_deleted(uint64_t id) {
   auto it = index_of_.find(id);
   if (it == index_of_.end()) return FVDB_E_NOT_FOUND;
   deleted_[it->second] = 1;
-  if (graph_ && !graph_dirty_) fvdb_graph_set_deleted(graph_, it->second, 1);
+  if (graph_ && !host_ahead_) fvdb_graph_set_deleted(graph_, it->second, 1);
   return FVDB_OK;
 }
 bool HNSWIndex::is_deleted(uint64_t id) const {
@@ -513,27 +515,63 @@ void HNSWIndex::lane_advance(Lane& ln, const float* q, bool q_on_device, uint32_
   ln.done = true;
 }
 
-// mirror the adjacency lists into HBM (only when they changed)
+int HNSWIndex::ensure_graph_handle() {
+  if (graph_) return FVDB_OK;
+  int rc = fvdb_graph_create(store_, &graph_);
+  if (rc) return rc;
+  return fvdb_graph_configure(graph_, cfg_.max_connections, cfg_.max_connections_layer_0);
+}
+
+// host -> device: install the whole graph, once, when nbrs_ holds changes the device has not seen
 int HNSWIndex::sync_graph() {
-  std::lock_guard<std::mutex> lk(sync_mu_);  // the first of several concurrent searches after a mutation uploads
-  if (!graph_) {
-    int rc = fvdb_graph_create(store_, &graph_);
-    if (rc) return rc;
-  }
-  if (!graph_dirty_) return FVDB_OK;
+  std::lock_guard<std::mutex> lk(sync_mu_);  // the first of several concurrent searches after such a change uploads
+  int rc = ensure_graph_handle();
+  if (rc) return rc;
+  if (!host_ahead_) return FVDB_OK;
   const uint32_t n = (uint32_t)ids_.size();
+  if (n == 0) {
+    host_ahead_ = false;
+    return FVDB_OK;
+  }
   std::vector<uint32_t> slot_start, adj;
   slot_start.reserve(graph_slots() + 1);
-  adj.reserve(graph_edges());
+  uint64_t edges = 0;
+  for (const auto& nd : nbrs_)
+    for (const auto& l : nd) edges += l.size();
+  adj.reserve(edges);
   for (uint32_t i = 0; i < n; ++i)
     for (uint32_t l = 0; l <= level_[i]; ++l) {
       slot_start.push_back((uint32_t)adj.size());
       adj.insert(adj.end(), nbrs_[i][l].begin(), nbrs_[i][l].end());
     }
   slot_start.push_back((uint32_t)adj.size());
-  int rc = fvdb_graph_upload(graph_, n, level_.data(), deleted_.data(), slot_start.data(), adj.data(), entry_);
+  rc = fvdb_graph_upload(graph_, n, level_.data(), deleted_.data(), slot_start.data(), adj.data(), entry_);
   if (rc) return rc;
-  graph_dirty_ = false;
+  host_ahead_ = false;
+  return FVDB_OK;
+}
+
+// device -> host: pull the lists device inserts have made
+int HNSWIndex::ensure_host_graph() {
+  std::lock_guard<std::mutex> lk(sync_mu_);
+  if (!dev_ahead_) return FVDB_OK;
+  const uint32_t n = (uint32_t)ids_.size();
+  uint64_t slots = 0;
+  for (uint32_t i = 0; i < n; ++i) slots += level_[i] + 1;
+  std::vector<uint32_t> slot_start(slots + 1);
+  uint64_t edges = 0;
+  int rc = fvdb_graph_download(graph_, slot_start.data(), nullptr, 0, &edges);
+  if (rc) return rc;
+  std::vector<uint32_t> adj(std::max<uint64_t>(edges, 1));
+  rc = fvdb_graph_download(graph_, slot_start.data(), adj.data(), adj.size(), &edges);
+  if (rc) return rc;
+  uint64_t sidx = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    nbrs_[i].resize(level_[i] + 1);
+    for (uint32_t l = 0; l <= level_[i]; ++l, ++sidx)
+      nbrs_[i][l].assign(adj.begin() + slot_start[sidx], adj.begin() + slot_start[sidx + 1]);
+  }
+  dev_ahead_ = false;
   return FVDB_OK;
 }
 
@@ -610,6 +648,8 @@ int HNSWIndex::finish_failed(const float* q, bool q_on_device, uint32_t dim, uin
                              float* dist, uint32_t* counts, const std::vector<uint32_t>& failed) {
   if (failed.empty()) return FVDB_OK;
   n_fallback_ += failed.size();
+  int rcg = ensure_host_graph();
+  if (rcg) return rcg;
   std::lock_guard<std::mutex> lk(walk_mu_);  // the host walk's lanes and scorer are one set per index
   std::vector<float> hq((size_t)failed.size() * dim);
   for (size_t i = 0; i < failed.size(); ++i) {
@@ -665,6 +705,8 @@ int HNSWIndex::search_impl(const float* q, bool q_on_device, uint32_t B, uint32_
   // (HybridIndex gives each of its concurrent searches a slot of its own through search_dev_begin/_end)
   std::lock_guard<std::mutex> serial(search_mu_);
   if (!device_path_ok(ef)) {
+    int rcg = ensure_host_graph();
+    if (rcg) return rcg;
     std::lock_guard<std::mutex> lk(walk_mu_);
     return search_host_walk(q, q_on_device, B, k, ef, ids, dist, counts);
   }
@@ -774,15 +816,175 @@ int HNSWIndex::score_pairs_from_row(uint32_t base_row, const std::vector<uint32_
 // --------------------------------------------------------------------------------------------
 // insert (src/hnsw/core.rs:226-378)
 // --------------------------------------------------------------------------------------------
-int HNSWIndex::insert(uint64_t id, const float* v, uint32_t dim, int64_t forced_level) {
+// the reference's checks, in its order (:227-245); non-finite values would panic its partial_cmp().unwrap()
+int HNSWIndex::check_insert(uint64_t id, const float* v, uint32_t dim) const {
   if (index_of_.count(id)) return FVDB_E_DUPLICATE;
   if (has_dim_ && dim != dim_) return FVDB_E_DIM;
   if (entry_lost_) return FVDB_E_NOT_FOUND;  // the reference unwraps the missing entry node here (:268-274)
-  if (!has_dim_) {
-    dim_ = dim;
-    has_dim_ = true;
+  for (uint32_t j = 0; j < dim; ++j)
+    if (!(v[j] - v[j] == 0.0f)) return FVDB_E_NONFINITE;
+  return FVDB_OK;
+}
+
+bool HNSWIndex::device_insert_ok() const {
+  static const bool env_off = getenv("FVDB_HNSW_DEVICE_INSERT") && atoi(getenv("FVDB_HNSW_DEVICE_INSERT")) == 0;
+  return device_insert_ && !env_off && cfg_.max_connections <= 63 && cfg_.max_connections_layer_0 <= 63 &&
+         cfg_.ef_construction >= 1 && cfg_.ef_construction <= 512 && dim_ <= 1024;
+}
+
+int HNSWIndex::insert(uint64_t id, const float* v, uint32_t dim, int64_t forced_level) {
+  uint64_t ok = 0;
+  int err = 0;
+  int rc = batch_insert(&id, v, 1, dim, &forced_level, &ok, &err);
+  return rc ? rc : err;
+}
+
+void HNSWIndex::finalize_insert(uint32_t row) {  // "nodes.insert(id, node)" (:367-370)
+  index_of_[ids_[row]] = row;
+  registered_[row] = 1;
+  n_registered_ += 1;
+}
+
+int HNSWIndex::batch_insert(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const int64_t* levels, uint64_t* n_ok,
+                            int* first_error) {
+  if (n_ok) *n_ok = 0;
+  if (first_error) *first_error = 0;
+  uint64_t ok = 0;
+  int err = 0;
+  auto finish = [&](int rc) {
+    if (n_ok) *n_ok = ok;
+    if (first_error) *first_error = err;
+    return rc;
+  };
+  for (uint64_t at = 0; at < n;) {
+    // the next run of inserts that pass the reference's checks (a failed insert draws no level and changes nothing)
+    std::vector<uint64_t> acc;
+    std::unordered_set<uint64_t> in_run;
+    uint64_t end = at;
+    for (; end < n && acc.size() < (1u << 20); ++end) {
+      int rc = check_insert(ids[end], v + end * dim, dim);
+      if (!rc && in_run.count(ids[end])) rc = FVDB_E_DUPLICATE;
+      if (rc) {
+        if (!err) err = rc;
+        continue;
+      }
+      if (!has_dim_) {
+        dim_ = dim;
+        has_dim_ = true;
+      }
+      in_run.insert(ids[end]);
+      acc.push_back(end);
+    }
+    at = end;
+    if (acc.empty()) continue;
+    if (!device_insert_ok()) {
+      for (uint64_t i : acc) {
+        int rc = insert_host(ids[i], v + i * dim, dim, levels ? levels[i] : -1);
+        if (rc == 0) ++ok;
+        else if (!err) err = rc;
+      }
+      continue;
+    }
+    int rc = ensure_store(dim);
+    if (rc) return finish(rc);
+    rc = sync_graph();  // the device rows must be current before they are edited in place
+    if (rc) return finish(rc);
+    const uint32_t m = (uint32_t)acc.size();
+    std::vector<uint32_t> lv(m);
+    for (uint32_t j = 0; j < m; ++j) {
+      const int64_t f = levels ? levels[acc[j]] : -1;
+      lv[j] = f >= 0 ? (uint32_t)f : (uint32_t)assign_level();
+    }
+    // vectors: one upload
+    const float* src = v + acc[0] * dim;
+    std::vector<float> packed;
+    if (acc.back() - acc[0] + 1 != m) {
+      packed.resize((size_t)m * dim);
+      for (uint32_t j = 0; j < m; ++j) std::memcpy(&packed[(size_t)j * dim], v + acc[j] * dim, (size_t)dim * 4);
+      src = packed.data();
+    }
+    uint64_t first64 = 0;
+    rc = fvdb_store_append(store_, src, m, &first64);
+    if (rc) return finish(rc);
+    const uint32_t first = (uint32_t)first64;
+    host_vecs_.insert(host_vecs_.end(), src, src + (size_t)m * dim);
+    for (uint32_t j = 0; j < m; ++j) {
+      ids_.push_back(ids[acc[j]]);
+      level_.push_back(lv[j]);
+      deleted_.push_back(0);
+      registered_.push_back(0);  // "not yet in the nodes map" while its links are being made (:370)
+      nbrs_.emplace_back(lv[j] + 1);
+    }
+    rc = fvdb_graph_append_nodes(graph_, first, m, lv.data());
+    if (rc) return finish(rc);
+    uint32_t done = 0;
+    while (done < m) {
+      uint32_t nd = 0;
+      fvdb_graph_insert_stats st{};
+      rc = fvdb_graph_insert_linked(graph_, first + done, m - done, cfg_.ef_construction, insert_mode_, &nd, &st);
+      if (rc) return finish(rc);
+      insert_stats_.n_done += st.n_done;
+      insert_stats_.speculated_ok += st.speculated_ok;
+      insert_stats_.searched_in_commit += st.searched_in_commit;
+      insert_stats_.commit_stops += st.commit_stops;
+      insert_stats_.rounds += st.rounds;
+      insert_stats_.expanded += st.expanded;
+      insert_stats_.rows_scored += st.rows_scored;
+      insert_stats_.tie_restarts += st.tie_restarts;
+      insert_stats_.launches += st.launches;
+      n_dist_ += st.rows_scored;  // of the searches the commit workgroup ran (speculated ones are not counted)
+      n_hops_ += st.rounds;
+      for (uint32_t j = 0; j < nd; ++j) finalize_insert(first + done + j);
+      done += nd;
+      dev_ahead_ = dev_ahead_ || nd > 0;
+      uint32_t e = FVDB_NO_ROW;
+      fvdb_graph_entry(graph_, &e, nullptr);
+      if (e != FVDB_NO_ROW) {
+        entry_ = e;
+        has_entry_ = true;
+      }
+      if (done < m && st.needs_host) {  // level >= 16 or an on-chip heap outgrown: this node takes the host algorithm
+        const uint32_t row = first + done;
+        rc = ensure_host_graph();
+        if (rc) return finish(rc);
+        std::vector<std::pair<uint32_t, uint32_t>> touched;
+        rc = link_host(row, &touched);
+        if (rc) return finish(rc);
+        finalize_insert(row);
+        rc = push_lists(touched);
+        if (rc) return finish(rc);
+        rc = fvdb_graph_set_entry(graph_, entry_, row + 1);
+        if (rc) return finish(rc);
+        n_host_inserts_ += 1;
+        done += 1;
+      } else if (nd == 0 && done < m) {
+        return finish(FVDB_E_HIP);  // no progress and no request for the host path: never expected
+      }
+    }
+    ok += m;
   }
+  return finish(FVDB_OK);
+}
+
+// rows `touched` (node, layer) -> the device graph
+int HNSWIndex::push_lists(const std::vector<std::pair<uint32_t, uint32_t>>& touched) {
+  std::vector<uint32_t> nodes, layers, off{0}, flat;
+  for (const auto& t : touched) {
+    nodes.push_back(t.first);
+    layers.push_back(t.second);
+    const auto& l = nbrs_[t.first][t.second];
+    flat.insert(flat.end(), l.begin(), l.end());
+    off.push_back((uint32_t)flat.size());
+  }
+  if (flat.empty()) flat.push_back(0);
+  return fvdb_graph_set_lists(graph_, (uint32_t)nodes.size(), nodes.data(), layers.data(), off.data(), flat.data());
+}
+
+// one insert by the host algorithm (the other mode; also dims / degree caps the device insert does not take)
+int HNSWIndex::insert_host(uint64_t id, const float* v, uint32_t dim, int64_t forced_level) {
   int rc = ensure_store(dim);
+  if (rc) return rc;
+  rc = ensure_host_graph();
   if (rc) return rc;
   const uint32_t level = forced_level >= 0 ? (uint32_t)forced_level : (uint32_t)assign_level();
   uint32_t row = 0;
@@ -793,14 +995,35 @@ int HNSWIndex::insert(uint64_t id, const float* v, uint32_t dim, int64_t forced_
   deleted_.push_back(0);
   registered_.push_back(0);  // "not yet in the nodes map" while its links are being made (:370)
   nbrs_.emplace_back(level + 1);
+  std::vector<std::pair<uint32_t, uint32_t>> touched;
+  rc = link_host(row, &touched);
+  if (rc) return rc;
+  finalize_insert(row);
+  n_host_inserts_ += 1;
+  if (graph_ && !host_ahead_) {  // the device copy agrees with nbrs_ up to this insert: patch the rows it changed
+    rc = fvdb_graph_append_nodes(graph_, row, 1, &level);
+    if (rc) return rc;
+    rc = push_lists(touched);
+    if (rc) return rc;
+    rc = fvdb_graph_set_entry(graph_, entry_, row + 1);
+    if (rc) return rc;
+  } else {
+    host_ahead_ = true;
+  }
+  return FVDB_OK;
+}
 
+int HNSWIndex::link_host(uint32_t row, std::vector<std::pair<uint32_t, uint32_t>>* touched) {
+  const uint32_t level = level_[row];
   bool is_first = false;
   if (!has_entry_) {
     has_entry_ = true;
     entry_ = row;
     is_first = true;
   }
+  for (uint32_t lc = 0; lc <= level; ++lc) touched->push_back({row, lc});
   uint32_t entry_level = 0;
+  int rc = FVDB_OK;
   if (!is_first) {
     const uint32_t ep = entry_;
     entry_level = level_[ep];
@@ -832,6 +1055,7 @@ int HNSWIndex::insert(uint64_t id, const float* v, uint32_t dim, int64_t forced_
         if (!registered_[nbv]) continue;
         if (level_[nbv] >= lc) {
           set_insert(nbrs_[nbv][lc], row);
+          touched->push_back({nbv, lc});
           if (nbrs_[nbv][lc].size() > m) to_prune.push_back(nbv);
         }
       }
@@ -853,10 +1077,6 @@ int HNSWIndex::insert(uint64_t id, const float* v, uint32_t dim, int64_t forced_
       }
     }
   }
-  index_of_[id] = row;
-  registered_[row] = 1;
-  n_registered_ += 1;
-  graph_dirty_ = true;
   if (!is_first && level > entry_level) entry_ = row;  // :372-375
   return FVDB_OK;
 }
@@ -900,7 +1120,7 @@ int HNSWIndex::restore(const uint64_t* ids, const float* v, uint64_t n, uint32_t
   if (it == index_of_.end()) return FVDB_E_NOT_FOUND;
   entry_ = it->second;
   has_entry_ = true;
-  graph_dirty_ = true;
+  host_ahead_ = true;
   return FVDB_OK;
 }
 
@@ -908,6 +1128,7 @@ int HNSWIndex::restore(const uint64_t* ids, const float* v, uint64_t n, uint32_t
 // unreferenced (the row store is append-only); `registered_ == 0` is this mirror's "nodes.get() == None".  The
 // reference does not repair an entry point that was removed: its searches then fail and its insert panics.
 uint64_t HNSWIndex::vacuum() {
+  if (ensure_host_graph()) return 0;
   std::vector<uint8_t> dead(ids_.size(), 0);
   uint64_t removed = 0;
   for (size_t i = 0; i < ids_.size(); ++i)
@@ -929,7 +1150,7 @@ uint64_t HNSWIndex::vacuum() {
   }
   n_registered_ -= removed;
   if (has_entry_ && dead[entry_]) entry_lost_ = true;
-  graph_dirty_ = true;
+  host_ahead_ = true;
   return removed;
 }
 
@@ -939,13 +1160,15 @@ uint64_t HNSWIndex::graph_slots() const {
     if (registered_[i]) s += level_[i] + 1;
   return s;
 }
-uint64_t HNSWIndex::graph_edges() const {
+uint64_t HNSWIndex::graph_edges() {
+  if (ensure_host_graph()) return 0;
   uint64_t e = 0;
   for (const auto& n : nbrs_)
     for (const auto& l : n) e += l.size();
   return e;
 }
-void HNSWIndex::export_graph(uint64_t* ids, uint32_t* levels, uint64_t* nbr_offsets, uint64_t* nbrs) const {
+void HNSWIndex::export_graph(uint64_t* ids, uint32_t* levels, uint64_t* nbr_offsets, uint64_t* nbrs) {
+  (void)ensure_host_graph();
   uint64_t slot = 0, e = 0, w = 0;
   for (size_t i = 0; i < ids_.size(); ++i) {
     if (!registered_[i]) continue;  // vacuumed
@@ -1044,7 +1267,7 @@ int HNSWIndex::bulk_build(const uint64_t* ids, const float* v, uint64_t n, uint3
     fvdb_ivf_destroy(flat);
     if (rc) return rc;
   }
-  graph_dirty_ = true;
+  host_ahead_ = true;
   return FVDB_OK;
 }
 

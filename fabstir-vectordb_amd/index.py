@@ -65,6 +65,9 @@ HOST_SIGNATURES = {
     "fvh_hnsw_set_threads": (None, [vp, i32]),
     "fvh_hnsw_dimension": (u32, [vp]),
     "fvh_hnsw_set_device_traversal": (None, [vp, i32]),
+    "fvh_hnsw_set_device_insert": (None, [vp, i32, i32]),
+    "fvh_hnsw_device_insert": (i32, [vp]),
+    "fvh_hnsw_insert_stats": (None, [vp, vp, u64p, u64p]),
     "fvh_hnsw_device_traversal": (i32, [vp]),
     "fvh_hnsw_device_fallbacks": (u64, [vp]),
     "fvh_hnsw_graph_kernel_times": (i32, [vp, f32p, u32p, u64p, u64p]),
@@ -429,6 +432,28 @@ class HNSWIndex(_Base):
 
     def device_traversal(self):
         return bool(self.lib.fvh_hnsw_device_traversal(self.h))
+
+    def set_device_insert(self, on, mode=0):
+        """True (default): an insert's searches, links and prunes run on the GPU against the adjacency in HBM
+        (fvdb_graph_insert_linked); False: the host algorithm with every distance batch scored on the GPU.
+        mode 0 = choose, 1 = one insert at a time, 2 = speculate batches.  The graph is identical."""
+        self.lib.fvh_hnsw_set_device_insert(self.h, int(bool(on)), int(mode))
+
+    def device_insert(self):
+        return bool(self.lib.fvh_hnsw_device_insert(self.h))
+
+    def insert_stats(self):
+        """Sums since construction: device-insert counters, inserts that took the host algorithm, and the
+        host -> device bytes of graph structure moved (levels, patched rows, whole-graph installs)."""
+        st = (C.c_uint32 * 10)()
+        host, up = C.c_uint64(0), C.c_uint64(0)
+        self.lib.fvh_hnsw_insert_stats(self.h, C.cast(st, C.c_void_p), C.byref(host), C.byref(up))
+        names = ("n_done", "needs_host", "speculated_ok", "searched_in_commit", "commit_stops", "rounds", "expanded",
+                 "rows_scored", "tie_restarts", "launches")
+        out = {k: int(v) for k, v in zip(names, st)}
+        out["host_path_inserts"] = host.value
+        out["graph_upload_bytes"] = up.value
+        return out
 
     def device_fallbacks(self):
         return int(self.lib.fvh_hnsw_device_fallbacks(self.h))

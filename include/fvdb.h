@@ -319,14 +319,14 @@ int fvdb_scorer_wait(fvdb_scorer* sc);
 typedef struct fvdb_graph fvdb_graph;
 int fvdb_graph_create(fvdb_store* s, fvdb_graph** out);
 void fvdb_graph_destroy(fvdb_graph* g);
-/* levels[n]; deleted[n] (0/1); slot_start[n_slots+1] / adj[]: CSR over (node, layer) slots in node
- * order, layer 0 first (n_slots = sum(level+1)); every list must hold <= 64 neighbours. */
+/* Install a whole graph (restore, bulk build, vacuum): levels[n]; deleted[n] (0/1); slot_start[n_slots+1] / adj[]: CSR
+ * over (node, layer) slots in node order, layer 0 first (n_slots = sum(level+1)); every list must hold <= 64 neighbours. */
 int fvdb_graph_upload(fvdb_graph* g, uint32_t n, const uint32_t* levels, const uint8_t* deleted,
                       const uint32_t* slot_start, const uint32_t* adj, uint32_t entry_node);
 int fvdb_graph_set_deleted(fvdb_graph* g, uint32_t node, int deleted);
 /* B queries (device, B x d).  out_nodes/out_dist: B x k device buffers, out_counts/out_status: B.
- * status 1 = the query overflowed the on-chip candidate heap / visited log and must be searched
- * through the host walk instead (its count is 0). */
+ * status 1 = the query overflowed the on-chip candidate heap and must be searched through the host walk
+ * instead (its count is 0). */
 int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_t k, uint32_t ef,
                           uint32_t* out_nodes_dev, float* out_dist_dev, uint32_t* out_counts_dev,
                           uint32_t* out_status_dev);
@@ -335,6 +335,43 @@ int fvdb_graph_search_dev(fvdb_graph* g, const float* q_dev, uint32_t B, uint32_
 int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const float* q_dev, uint32_t B, uint32_t k,
                                uint32_t ef, uint32_t* out_nodes_dev, float* out_dist_dev, uint32_t* out_counts_dev,
                                uint32_t* out_status_dev);
+/* ---- device-resident graph construction --------------------------------------------------------
+ * HNSWIndex::insert (src/hnsw/core.rs:226-378) with the graph resident in HBM: greedy descent, search_layer
+ * (ef_construction), select_neighbors (:556-558), back-links and prune_neighbors_with_new_node (:588-624) run in one
+ * workgroup per insert against the adjacency rows in HBM, strictly in insert order — the graph is the one the
+ * reference's sequential loop builds.  Adjacency rows have a fixed stride per (node, layer), so every mutation —
+ * this one, or a host-side insert patched in with fvdb_graph_set_lists — rewrites only the rows it touches.
+ *
+ * configure: the degree caps (max_connections, max_connections_layer_0; src/hnsw/core.rs:37-46) the row strides
+ *   are sized for; before the first node.
+ * append_nodes: store rows [first, first + n) become nodes with empty lists (levels[n]); first must equal the
+ *   current node count (node index = store row).
+ * insert_linked: links the appended, not yet linked nodes [first, first + n) in order.  mode 0 = choose,
+ *   1 = one insert at a time, 2 = speculate a batch of searches against the frozen graph and commit in order
+ *   (a speculated search is adopted only if no adjacency row it expanded was changed by an earlier insert of the
+ *   batch).  *n_done < n with stats->needs_host = 1: node first + *n_done needs the host path (level >= 16 or an
+ *   on-chip heap overflow); link it through fvdb_graph_set_lists / fvdb_graph_set_entry and call again.
+ * set_lists: overwrite the lists of n_lists (node, layer) rows: offsets[n_lists + 1] into nbrs[].
+ * set_entry: entry point + the number of nodes whose links are complete.
+ * download: the adjacency in CSR form over (node, layer) slots in node order (slot_start[slots + 1], adj[adj_cap];
+ *   either may be NULL), *n_edges = total.  upload_bytes: host -> device bytes of graph STRUCTURE moved so far. */
+typedef struct fvdb_graph_insert_stats {
+  uint32_t n_done, needs_host;
+  uint32_t speculated_ok, searched_in_commit, commit_stops;  /* speculation: adopted / searched by the commit workgroup / early stops */
+  uint32_t rounds, expanded, rows_scored, tie_restarts;      /* of the searches run by the commit workgroup */
+  uint32_t launches;
+} fvdb_graph_insert_stats;
+int fvdb_graph_configure(fvdb_graph* g, uint32_t max_connections, uint32_t max_connections_layer_0);
+int fvdb_graph_append_nodes(fvdb_graph* g, uint32_t first, uint32_t n, const uint32_t* levels);
+int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t ef_construction, int mode, uint32_t* n_done,
+                             fvdb_graph_insert_stats* stats);
+int fvdb_graph_set_lists(fvdb_graph* g, uint32_t n_lists, const uint32_t* nodes, const uint32_t* layers, const uint32_t* offsets,
+                         const uint32_t* nbrs);
+int fvdb_graph_set_entry(fvdb_graph* g, uint32_t entry_node, uint32_t n_linked);
+int fvdb_graph_entry(fvdb_graph* g, uint32_t* entry_node, uint32_t* n_nodes);
+int fvdb_graph_download(fvdb_graph* g, uint32_t* slot_start, uint32_t* adj, uint64_t adj_cap, uint64_t* n_edges);
+uint64_t fvdb_graph_upload_bytes(fvdb_graph* g);
+
 /* With profiling on (fvdb_ctx_set_profiling): summed duration (HIP events on the launch stream) of the last
  * <= 64 launches of the traversal kernel since the previous call, and how many were summed; and (always) the
  * rows scored and hops taken by all queries since the previous call (either may be NULL).  Synchronises. */

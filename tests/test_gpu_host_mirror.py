@@ -213,11 +213,22 @@ def test_device_traversal_overflow_falls_back_to_host_walk(fv, ctx, monkeypatch)
     gh.set_device_traversal(False)
     want = gh.search(q, 10, 100)
     gh.set_device_traversal(True)
-    monkeypatch.setenv("FVDB_GRAPH_TCAP", "40")  # visited log of 40 nodes: every query overflows
+    monkeypatch.setenv("FVDB_GRAPH_TCAP", "40")  # visited log of 40 nodes: every query outgrows it ...
+    got = gh.search(q, 10, 100)
+    assert gh.device_fallbacks() == 0             # ... and clears its whole map instead: still finished on the device
+    assert np.array_equal(got.ids, want.ids) and np.array_equal(bits(got.distances), bits(want.distances))
+    for ef in (100, 40):                          # restated-heap kernel / sorted-register kernel
+        got = gh.search(q, 10, ef)
+        gh.set_device_traversal(False)
+        w2 = gh.search(q, 10, ef)
+        gh.set_device_traversal(True)
+        assert np.array_equal(got.ids, w2.ids) and np.array_equal(bits(got.distances), bits(w2.distances))
+    monkeypatch.delenv("FVDB_GRAPH_TCAP")
+    monkeypatch.setenv("FVDB_GRAPH_CAND_CAP", "24")  # a candidate heap of 24 slots: every ef = 100 query overflows it
     got = gh.search(q, 10, 100)
     assert gh.device_fallbacks() == q.shape[0]
     assert np.array_equal(got.ids, want.ids) and np.array_equal(bits(got.distances), bits(want.distances))
-    monkeypatch.delenv("FVDB_GRAPH_TCAP")
+    monkeypatch.delenv("FVDB_GRAPH_CAND_CAP")
     again = gh.search(q, 10, 100)  # bitmaps were left clean by the aborted walks
     assert np.array_equal(again.ids, want.ids) and gh.device_fallbacks() == q.shape[0]
 
