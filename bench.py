@@ -81,6 +81,21 @@ class IsotropicGenerator:
         return np.ascontiguousarray(self.means[comp] + np.float32(self.sigma) * r.standard_normal((n, self.d), dtype=np.float32))
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` from a plain shell: the same command under torch.distributed.run, one rank per GPU,
+    rendezvous on 127.0.0.1.  The child's stdout (one JSON line) is passed through; its exit code is returned."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"launching {n} ranks: {' '.join(cmd)}")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def usable_cpus():
     """CPUs this process may use: min(affinity, cgroup quota) — the GPU box shows 256 and grants 16."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -135,6 +150,11 @@ def main():
     ap.add_argument("--hnsw-traversal", choices=["device", "host"], default="device",
                     help="device: the layered walk runs on the GPU (one launch per batch); host: on the host with one "
                          "candidate-scoring launch per hop (the north_star's split).  Identical results.")
+    ap.add_argument("--hnsw-graph", choices=["sequential", "bulk"], default="sequential",
+                    help="sequential: the reference's own build — HNSWIndex::insert in id order (src/hnsw/core.rs:226-378), "
+                         "device-resident; bulk: exact nearest-M per layer (an extension: another graph)")
+    ap.add_argument("--insert-sample", type=int, default=2048,
+                    help="inserts timed on GPU and CPU oracle at the full graph size for the insert_path object (0 = skip)")
     ap.add_argument("--compare-host-walk", type=int, default=3, help="extra steps timed with the host walk (0 = skip)")
     ap.add_argument("--parts", choices=["both", "recent", "historical"], default="both",
                     help="development aid: time only the HNSW or only the IVF part of the hybrid search (recall is then meaningless)")
@@ -143,6 +163,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="multi-GPU: see the module docstring")
     ap.add_argument("--transport", choices=["rccl", "hosted"], default=os.environ.get("FVDB_TRANSPORT", "rccl"),
                     help="hosted: exchanges carried over torch.distributed on host buffers (several ranks on ONE GPU)")
+    ap.add_argument("--allow-hosted", action="store_true",
+                    help="multi-GPU: permit the hosted transport (asked for with --transport hosted, or as the fallback when "
+                         "RCCL cannot be brought up); without it such a run exits non-zero, so an n_gpus > 1 line is an RCCL line")
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--spread", type=float, default=1.5)
     ap.add_argument("--supplementary", action="store_true",
@@ -152,9 +175,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # called plainly with --gpus N: start one rank per GPU as a FRESH child process (this process has not touched the
+        # GPU and never will), relay its one JSON line, exit with its code
+        raise SystemExit(launch_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     dist = torch = None
     # stdout carries ONE JSON line and nothing else: libraries (gloo's "Rank 0 is connected to ..." lines, RCCL's version
@@ -205,6 +230,7 @@ def main():
     ctx_hnsw = fv.Context(local_rank)
     hyb = fv.HybridIndex(ctx_ivf, ctx_hnsw=ctx_hnsw, n_clusters=args.nlist, n_probe=min(32, args.nlist),
                          train_size=args.train_sample, max_iterations=25, ivf_seed=7, hnsw_seed=11)
+    hyb.set_sequential_graph(args.hnsw_graph == "sequential")
     t0 = time.time()
     sample = x[np.random.Generator(np.random.Philox(key=5)).choice(N, min(args.train_sample, N), replace=False)]
     hyb.initialize(sample)
@@ -218,7 +244,11 @@ def main():
         hyb.bulk_insert(ids, x, ts, now)
     else:
         if world > 1:
-            comm, transport_used = sh.bring_up(ctx_ivf, dist, torch, args.transport, log=log)
+            try:
+                comm, transport_used = sh.bring_up(ctx_ivf, dist, torch, args.transport, log=log, allow_hosted=args.allow_hosted)
+            except sh.BringUpFailed as e:
+                log(f"FATAL: {e}")
+                os._exit(3)  # every rank takes this exit (the decision is an all-reduce): no JSON line is printed
         else:
             comm, transport_used = sh.Comm.rccl(ctx_ivf, dist, torch), "rccl"
             sh.self_test(comm)
@@ -226,8 +256,9 @@ def main():
         sharded.bulk_insert(ids, x, ts, now)
         if dist is not None:
             dist.barrier()
-    log(f"index build (HNSW bulk graph {hyb.recent_count()} nodes + IVF {hyb.historical_count()} rows): "
-        f"{time.time() - t0:.1f}s")
+    graph_build_s = hyb.recent_build_seconds()
+    log(f"index build (HNSW {args.hnsw_graph} graph {hyb.recent_count()} nodes in {graph_build_s:.1f}s + IVF "
+        f"{hyb.historical_count()} rows): {time.time() - t0:.1f}s; insert stats {hyb.hnsw().insert_stats()}")
 
     # ---- exact ground truth on the GPU (flat scan of all N rows) ----
     t0 = time.time()
@@ -422,9 +453,11 @@ def main():
         roofline["frac_alone"] = round(roofline["bytes_per_launch"] / (graph_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
 
     # ---- CPU baseline: the oracle (reference algorithm restated) on the same structures ----
-    cpu = None
+    cpu = ins = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
-        cpu = cpu_baseline(fv, hyb, x, ids, is_recent, now, queries[0], run(0, nprobe, ef), k, nprobe, ef, args)
+        cpu, oracle_hyb = cpu_baseline(fv, hyb, x, ids, is_recent, now, queries[0], run(0, nprobe, ef), k, nprobe, ef, args)
+        if args.insert_sample > 0:  # last: it grows the graph
+            ins = insert_path(hyb, oracle_hyb, gen, N, args.insert_sample, graph_build_s, args)
 
     supplementary = None
     if args.supplementary and world == 1:
@@ -447,7 +480,10 @@ def main():
             "config": {"workload": "c3: 1M x 384 f32 hybrid HNSW/IVF (10K-vector chunks), batch 1024, k 10",
                        "n_vectors": N, "dim": d, "batch": B, "global_batch": global_batch, "k": k, "recent_frac_hnsw": args.recent_frac,
                        "nlist": args.nlist, "nprobe": nprobe, "hnsw_ef": ef, "hnsw_M": 16, "hnsw_M0": 32,
-                       "hnsw_graph": "bulk_build: every layer member linked to its exact nearest M (M0) members",
+                       "hnsw_graph": ("sequential insert: the reference's HNSWIndex::insert in id order, ef_construction 200, "
+                                      "device-resident (fvdb_graph_insert_linked)") if args.hnsw_graph == "sequential" else
+                                     "bulk_build: every layer member linked to its exact nearest M (M0) members",
+                       "hnsw_graph_build_s": round(graph_build_s, 2),
                        "hnsw_traversal": args.hnsw_traversal, "batches_in_flight": depth, "query_batches": nb,
                        "host_collect_merge_ms_per_step": None if host_collect_ms is None else round(host_collect_ms, 4),
                        "other_traversal_mode": other, "hnsw_device_fallbacks": hnsw.device_fallbacks(),
@@ -458,7 +494,7 @@ def main():
                                     f"unit within-comp sigma, orthonormal embedding into {d}-d + 0.02 ambient noise",
                        "transport": None if world == 1 and not force_sharded else transport_used,
                        "parallelism": par},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "insert_path": ins,
         }
         if supplementary is not None:
             out["supplementary"] = supplementary
@@ -568,7 +604,48 @@ def cpu_baseline(fv, hyb, x, ids, is_recent, now, q0, gpu_res, k, nprobe, ef, ar
         f"gpu==oracle on the sample: {same}")
     return {"value": round(ns / tall, 2), "unit": "queries/s", "cores": threads, "kind": "port",
             "sample": f"{ns} queries of the first batch, same index structures and (nprobe, ef); one query per thread",
-            "single_thread_value": round(max(8, ns // 8) / t1, 2), "gpu_matches_oracle_on_sample": same}
+            "single_thread_value": round(max(8, ns // 8) / t1, 2), "gpu_matches_oracle_on_sample": same}, o
+
+
+def insert_path(hyb, oracle_hyb, gen, N, n_ins, graph_build_s, args):
+    """addVectors' path (HNSWIndex::insert, src/hnsw/core.rs:226-378; every addVectors row goes to the HNSW part,
+    src/hybrid/core.rs:391-399): `n_ins` fresh rows inserted in order into the benchmark's graph at its full size — on
+    the GPU (device-resident insert) and by the CPU oracle holding the same graph — timed, and the resulting lists compared."""
+    import oracle as orc
+    hn, oh = hyb.hnsw(), oracle_hyb.hnsw()
+    n_graph = hn.node_count()
+    rows = gen.rows(n_ins, stream=20_000_000)
+    new_ids = np.arange(N, N + n_ins, dtype=np.uint64)
+    levels = orc.rng_levels(4242, n_ins)
+    before = hn.insert_stats()
+    t0 = time.perf_counter()
+    ok, bad = hn.batch_insert(new_ids, rows, levels)
+    t_gpu = time.perf_counter() - t0
+    after = hn.insert_stats()
+    t0 = time.perf_counter()
+    oh.batch_insert(new_ids, rows, levels)
+    t_cpu = time.perf_counter() - t0
+    same = ok == n_ins and hn.entry_point() == oh.entry_point()
+    for i, lv in zip(new_ids.tolist(), levels.tolist()):
+        for layer in range(int(lv) + 1):
+            nb = hn.neighbors(i, layer)
+            same = same and nb == oh.neighbors(i, layer)
+            if layer == 0:  # the rows the insert linked back and pruned
+                for j in nb[:4]:
+                    same = same and hn.neighbors(j, 0) == oh.neighbors(j, 0)
+    stats = {k_: after[k_] - before[k_] for k_ in ("speculated_ok", "searched_in_commit", "commit_stops", "tie_restarts",
+                                                    "launches", "host_path_inserts")}
+    log(f"insert path at {n_graph} nodes: GPU {n_ins / t_gpu:.0f} inserts/s, CPU oracle (1 core) {n_ins / t_cpu:.0f} inserts/s, "
+        f"lists identical: {same}; {stats}")
+    return {"value": round(n_ins / t_gpu, 1), "unit": "inserts/s", "graph_nodes": n_graph, "hnsw_M": 16, "hnsw_M0": 32,
+            "ef_construction": 200,
+            "sample": f"{n_ins} fresh rows inserted in order into the benchmark's graph (one batch_insert call; vectors uploaded "
+                      f"inside the timed region)",
+            "cpu_value": round(n_ins / t_cpu, 1), "cpu_cores": 1, "cpu_kind": "port",
+            "cpu_note": "the reference's insert is sequential by construction: one core",
+            "graph_matches_oracle_on_sample": bool(same), "device_insert": stats,
+            "whole_build": {"nodes": n_graph, "seconds": round(graph_build_s, 2),
+                            "inserts_per_s": round(n_graph / max(graph_build_s, 1e-9), 1), "graph": args.hnsw_graph}}
 
 
 def run_supplementary(fv, ctx, args):

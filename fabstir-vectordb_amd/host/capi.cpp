@@ -272,6 +272,9 @@ uint64_t fvh_hybrid_historical_count(void* p) { return ((HybridIndex*)p)->histor
 int fvh_hybrid_is_initialized(void* p) { return ((HybridIndex*)p)->is_initialized(); }
 int fvh_hybrid_is_ivf_trained(void* p) { return ((HybridIndex*)p)->is_ivf_trained(); }
 void* fvh_hybrid_hnsw(void* p) { return &((HybridIndex*)p)->recent(); }
+void fvh_hybrid_set_sequential_graph(void* p, int on) { ((HybridIndex*)p)->set_sequential_graph(on != 0); }
+int fvh_hybrid_sequential_graph(void* p) { return ((HybridIndex*)p)->sequential_graph(); }
+double fvh_hybrid_recent_build_seconds(void* p) { return ((HybridIndex*)p)->recent_build_seconds(); }
 void* fvh_hybrid_ivf(void* p) { return &((HybridIndex*)p)->historical(); }
 
 }  // extern "C"

@@ -414,6 +414,12 @@ class HybridIndex {
   void export_timestamps(uint64_t* ids, double* ts) const;  // insertion order
   HNSWIndex& recent() { return *recent_; }
   IVFIndex& historical() { return *historical_; }
+  // How the bulk loaders build the graph of the recent part: true (default) = the reference's own build, sequential
+  // inserts in id order (HNSWIndex::batch_insert, on the device); false = HNSWIndex::bulk_build (exact nearest-M
+  // per layer — a different graph, an extension).
+  void set_sequential_graph(bool on) { sequential_graph_ = on; }
+  bool sequential_graph() const { return sequential_graph_; }
+  double recent_build_seconds() const { return recent_build_s_; }  // wall time of the last bulk load's graph build
   // bulk loaders for scale runs: route by age like insert_with_timestamp, batched on the GPU
   int bulk_insert(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const double* ts, double now);
   // Multi-GPU placement: the same, but of the historical rows only those whose IVF list is owned by
@@ -429,6 +435,9 @@ class HybridIndex {
                   double now, uint64_t* ids, float* dist, uint32_t* counts);
   int begin_impl(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
                  int shard_mode = -1);
+  int build_recent(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim);
+  bool sequential_graph_ = true;
+  double recent_build_s_ = 0.0;
   fvdb_comm* comm_ = nullptr;
   fvdb_sharded* sharded_ = nullptr;
   uint64_t migrate_locked(double threshold_s, double now);

@@ -1,6 +1,7 @@
 // hybrid_index.cpp — HybridIndex mirror (src/hybrid/core.rs): age routing, per-search
 // auto-migration, HNSW + IVF search and the stable merge.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -75,7 +76,21 @@ int HybridIndex::insert_with_timestamp(uint64_t id, const float* v, uint32_t dim
   return FVDB_OK;
 }
 
-// Scale loader: same routing as insert_with_timestamp, but the HNSW part is bulk-built and the
+// the recent part of a bulk load: the reference's sequential inserts (levels drawn in order), or the exact nearest-M graph
+int HybridIndex::build_recent(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim) {
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc, err = 0;
+  if (!sequential_graph_) {
+    rc = recent_->bulk_build(ids, v, n, dim, nullptr);
+  } else {
+    uint64_t ok = 0;
+    rc = recent_->batch_insert(ids, v, n, dim, nullptr, &ok, &err);
+  }
+  recent_build_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return rc ? rc : err;
+}
+
+// Scale loader: same routing as insert_with_timestamp, but the HNSW part is built in one call (build_recent) and the
 // IVF part is assigned/appended in one GPU pass.  Only valid on an index with no vectors yet.
 int HybridIndex::bulk_insert(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim, const double* ts,
                              double now) {
@@ -95,7 +110,7 @@ int HybridIndex::bulk_insert(const uint64_t* ids, const float* v, uint64_t n, ui
   }
   ts_order_.assign(ids, ids + n);
   if (!rid.empty()) {
-    int rc = recent_->bulk_build(rid.data(), rv.data(), rid.size(), dim, nullptr);
+    int rc = build_recent(rid.data(), rv.data(), rid.size(), dim);
     if (rc) return rc;
     recent_count_ = rid.size();
     for (uint64_t i = 0; i < n; ++i)
@@ -150,7 +165,7 @@ int HybridIndex::bulk_insert_sharded(const uint64_t* ids, const float* v, uint64
   }
   ts_order_.assign(ids, ids + n);
   if (!rid.empty()) {  // replicated graph: every rank builds the same one
-    int rc = recent_->bulk_build(rid.data(), rv.data(), rid.size(), dim, nullptr);
+    int rc = build_recent(rid.data(), rv.data(), rid.size(), dim);
     if (rc) return rc;
     recent_count_ = rid.size();
     for (uint64_t i = 0; i < n; ++i)

@@ -105,6 +105,9 @@ HOST_SIGNATURES = {
     "fvh_hybrid_is_initialized": (i32, [vp]),
     "fvh_hybrid_is_ivf_trained": (i32, [vp]),
     "fvh_hybrid_hnsw": (vp, [vp]),
+    "fvh_hybrid_set_sequential_graph": (None, [vp, i32]),
+    "fvh_hybrid_sequential_graph": (i32, [vp]),
+    "fvh_hybrid_recent_build_seconds": (dbl, [vp]),
     "fvh_hybrid_ivf": (vp, [vp]),
 }
 
@@ -517,6 +520,17 @@ class HybridIndex(_Base):
 
     def insert(self, id, vector, now=0.0, level=-1):
         self.insert_with_timestamp(id, vector, now, now, level)
+
+    def set_sequential_graph(self, on):
+        """How bulk_insert builds the recent part's graph: True (default) = the reference's sequential inserts
+        (device-resident), False = HNSWIndex.bulk_build (exact nearest-M per layer: an extension, another graph)."""
+        self.lib.fvh_hybrid_set_sequential_graph(self.h, int(bool(on)))
+
+    def sequential_graph(self):
+        return bool(self.lib.fvh_hybrid_sequential_graph(self.h))
+
+    def recent_build_seconds(self):
+        return float(self.lib.fvh_hybrid_recent_build_seconds(self.h))
 
     def bulk_insert(self, ids, vectors, timestamps, now):
         v = _rows(vectors)

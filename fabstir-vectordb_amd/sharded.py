@@ -169,11 +169,19 @@ def self_test(comm):
         raise RuntimeError(f"rank {r}: communicator self-test moved wrong data")
 
 
-def bring_up(ctx, dist, torch, transport="rccl", timeout_s=180.0, log=print):
-    """The communicator a multi-rank launcher should use: RCCL, created and self-tested under a watchdog; when any rank
-    fails (or does not finish in `timeout_s`) EVERY rank switches to the hosted transport — same C data path, the two
-    exchanges carried by `dist` on host buffers — and says so loudly.  Returns (comm, transport actually in use)."""
+class BringUpFailed(RuntimeError):
+    """RCCL could not be brought up on every rank and the caller did not allow the hosted transport."""
+
+
+def bring_up(ctx, dist, torch, transport="rccl", timeout_s=180.0, log=print, allow_hosted=False):
+    """The communicator a multi-rank launcher should use: RCCL, created and self-tested under a watchdog.  When any rank
+    fails (or does not finish in `timeout_s`) EVERY rank raises BringUpFailed — a multi-GPU number can then only come
+    from RCCL — unless `allow_hosted`, in which case every rank switches to the hosted transport (same C data path, the
+    exchanges carried by `dist` on host buffers) and says so loudly.  transport="hosted" asks for that transport
+    outright and also needs `allow_hosted`.  Returns (comm, transport actually in use)."""
     if transport == "hosted":
+        if not allow_hosted:
+            raise BringUpFailed("the hosted transport is a rehearsal aid: pass allow_hosted / --allow-hosted to use it")
         return Comm.hosted(ctx, dist, torch), "hosted"
     import threading
     box = {}
@@ -195,6 +203,8 @@ def bring_up(ctx, dist, torch, transport="rccl", timeout_s=180.0, log=print):
     if int(flag.item()) == 1:
         return box["comm"], "rccl"
     why = box.get("err", "timed out" if t.is_alive() else "another rank failed")
+    if not allow_hosted:
+        raise BringUpFailed(f"RCCL bring-up FAILED on at least one rank (this rank: {why})")
     log(f"RCCL bring-up FAILED on at least one rank (this rank: {why}); every rank continues on the HOSTED transport")
     return Comm.hosted(ctx, dist, torch), "hosted (RCCL bring-up failed)"
 

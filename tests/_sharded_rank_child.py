@@ -42,7 +42,7 @@ def main():
     hyb = fv.HybridIndex(ctx, max_connections=8, max_connections_layer_0=16, ef_construction=40, n_clusters=nlist,
                          n_probe=nprobe, hnsw_seed=19)
     hyb.set_ivf_centroids(cents)
-    comm, used = sh.bring_up(ctx, dist, torch, "hosted")
+    comm, used = sh.bring_up(ctx, dist, torch, "hosted", allow_hosted=True)
     assert used == "hosted"
     sh.self_test(comm)  # the launcher's bring-up check: rank-stamped words through both exchange kinds
     S = sh.ShardedHybrid(hyb, comm)

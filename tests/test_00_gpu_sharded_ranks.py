@@ -51,3 +51,38 @@ def test_every_rank_of_the_sharded_search_matches_the_oracle(tmp_path, world):
         assert rep["scan_fallbacks"] * 5 <= rep["queries_scanned"], rep  # the filter decides, not the exact rescan
     owned = [json.load(open(tmp_path / f"rank{r}.json"))["lists_owned"] for r in range(world)]
     assert sum(owned) == 24 and min(owned) > 0
+
+
+def _bench(args, timeout=900):
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--n-vectors", "40000", "--nlist", "64", "--steps", "4", "--warmup", "1",
+           "--query-batches", "2", "--select-batches", "1", "--train-sample", "10000", "--batch", "128", "--nprobe", "16", "--ef", "50",
+           "--no-cpu-baseline", "--compare-host-walk", "0"] + args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=root)
+
+
+def test_bench_gpus_n_launches_itself_from_a_plain_shell():
+    # the driver's call: `python bench.py --gpus N ...` with no torchrun around it.  The parent starts the ranks as a
+    # fresh child before touching the GPU and relays exactly one JSON line.  Two ranks share the box's one GPU here, so
+    # the transport is the hosted one and has to be allowed explicitly.
+    if _gpu_initialised_here():
+        pytest.skip("this process already holds the GPU; run this module first (it sorts first by name)")
+    p = _bench(["--gpus", "2", "--transport", "hosted", "--allow-hosted"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[:2000]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["transport"] == "hosted" and j["value"] > 0
+    assert j["config"]["global_batch"] == 2 * 128 and j["scaling"] == "weak"
+
+
+def test_bench_refuses_a_multi_gpu_line_without_rccl():
+    # RCCL cannot place two ranks on one device: bring-up fails on every rank, and without --allow-hosted the run must
+    # exit non-zero and print no JSON line (an n_gpus > 1 line can only come from RCCL)
+    if _gpu_initialised_here():
+        pytest.skip("this process already holds the GPU; run this module first (it sorts first by name)")
+    p = _bench(["--gpus", "2"], timeout=600)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")], p.stdout[:2000]

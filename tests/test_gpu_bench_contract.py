@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_prints_one_json_line_with_the_contract_fields():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--n-vectors", "60000", "--nlist", "64", "--steps", "6",
            "--warmup", "1", "--query-batches", "4", "--select-batches", "2", "--cpu-sample", "64", "--compare-host-walk", "1",
-           "--train-sample", "20000", "--batch", "256"]
+           "--train-sample", "20000", "--batch", "256", "--insert-sample", "256"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
@@ -37,3 +37,11 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] == "port" and c["value"] > 0 and c["gpu_matches_oracle_on_sample"] is True
+    # addVectors' path: the headline's graph is the reference's sequential build, and further inserts at its full size are
+    # timed on the GPU beside the CPU oracle, with identical adjacency lists
+    assert j["config"]["hnsw_graph"].startswith("sequential insert")
+    ins = j["insert_path"]
+    for key in ("value", "unit", "graph_nodes", "sample", "cpu_value", "cpu_cores", "graph_matches_oracle_on_sample", "whole_build"):
+        assert key in ins, key
+    assert ins["unit"] == "inserts/s" and ins["value"] > 0 and ins["cpu_value"] > 0 and ins["cpu_cores"] == 1
+    assert ins["graph_matches_oracle_on_sample"] is True and ins["device_insert"]["host_path_inserts"] == 0

@@ -138,3 +138,33 @@ def test_sharded_ivf_scheme_world2_gloo(tmp_path):
     mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+def test_bench_launcher_starts_one_rank_per_gpu_as_a_child(monkeypatch):
+    # `python bench.py --gpus N` with no WORLD_SIZE: the parent builds the torch.distributed.run command line (one rank
+    # per GPU, rendezvous on 127.0.0.1), hands over its own arguments unchanged and returns the child's exit code —
+    # without importing the engine (no GPU call in the parent)
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "2"])
+    before = set(sys.modules)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert not any(m.startswith("fabstir_vectordb_amd") or m == "fvdb_import" for m in set(sys.modules) - before)
