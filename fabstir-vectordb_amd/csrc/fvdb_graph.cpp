@@ -520,7 +520,7 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
   if (st.n_linked != first) FAIL(ctx, FVDB_E_INVALID, "nodes are linked in store-row order");
   st.cursor = 0;
   st.status = 0;
-  st.n_valid = st.n_rerun = st.n_stopped = st.rounds = st.consumed = st.scored = st.ties = 0;
+  st.n_valid = st.n_rerun = st.n_stopped = st.rounds = st.consumed = st.scored = st.ties = st.spec_ties = 0;
   rc = push_state(g, st);
   if (rc) return rc;
   // speculation pays once an insert touches a small part of the graph (mode 0 = choose; 1 = never; 2 = always)
@@ -535,7 +535,8 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
   // in parallel, against the graph as it then stands
   const uint32_t max_rerun = env_rerun >= 0 ? (uint32_t)env_rerun : 0u;
   HIPCHK(ctx, g->d_spec.ensure((size_t)Kmax * kSpecWords * 4));
-  HIPCHK(ctx, g->d_elog.ensure((size_t)Kmax * kLogCap * 4));
+  HIPCHK(ctx, g->d_elog.ensure((size_t)Kmax * kBuildLayers * kLogCap * 4));
+  HIPCHK(ctx, hipMemsetAsync(g->d_spec.p, 0, (size_t)Kmax * kSpecWords * 4, ctx->stream));  // no stale "usable" flags
   FVDB_BUILD_SWITCH(s->dpad, {
     HIPCHK(ctx, hipFuncSetAttribute((const void*)hnsw_insert_commit_kernel<NB_, FULL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
     HIPCHK(ctx, hipFuncSetAttribute((const void*)hnsw_insert_search_kernel<NB_, FULL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
@@ -549,11 +550,14 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
 #endif
   fvdb_graph_insert_stats acc{};
   uint32_t done = 0;
+  uint32_t exact_positions = 4;  // speculated searches of a batch that may start again with the restated heaps on a tie
+  uint32_t ties_seen = 0;
   while (done < n) {
-    const bool speculate = mode == 2 || (mode == 0 && (uint64_t)first + done >= 2000 && n - done >= 8);
+    const bool speculate = mode == 2 || (mode == 0 && (uint64_t)first + done >= 1000 && n - done >= 8);
     uint32_t launches = 0;
     if (!speculate) {
-      const uint32_t chunk = std::min<uint32_t>(n - done, 2048);  // bounds one launch to a fraction of a second
+      uint32_t chunk = std::min<uint32_t>(n - done, 2048);  // bounds one launch to a fraction of a second
+      if (mode == 0 && (uint64_t)first + done < 1000) chunk = std::min<uint32_t>(chunk, 1000 - (first + done));
       g->tag += 1;
       const uint32_t tag = g->tag;
       FVDB_BUILD_SWITCH(s->dpad, {
@@ -567,8 +571,8 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
         g->tag += 1;
         const uint32_t tag = g->tag;
         FVDB_BUILD_SWITCH(s->dpad, {
-          hipLaunchKernelGGL((hnsw_insert_search_kernel<NB_, FULL_>), dim3(K), dim3(kBuildThreads), L.total, ctx->stream, v, first, n,
-                             g->d_spec.as<uint32_t>(), g->d_elog.as<uint32_t>());
+          hipLaunchKernelGGL((hnsw_insert_search_kernel<NB_, FULL_>), dim3(K, kBuildLayers), dim3(kBuildThreads), L.total, ctx->stream, v,
+                             first, n, exact_positions, tag, g->d_spec.as<uint32_t>(), g->d_elog.as<uint32_t>());
           hipLaunchKernelGGL((hnsw_insert_commit_kernel<NB_, FULL_>), dim3(1), dim3(kBuildThreads), L.total, ctx->stream, v, first, n, K,
                              tag, max_rerun, (const uint32_t*)g->d_spec.p, (const uint32_t*)g->d_elog.p);
         });
@@ -585,6 +589,11 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
       // (the slowest of the batch's searches sets the launch's duration)
       const uint32_t run = (st.cursor - before) / (launches / 2);
       K = std::min<uint32_t>(Kmax, std::max<uint32_t>(8, 2 * run + 4));
+    }
+    if (speculate && launches >= 2) {  // where ties are the rule (duplicate vectors) every speculation takes the exact search
+      const uint32_t searched = (launches / 2) * K, tied = st.spec_ties - ties_seen;
+      exact_positions = 4 * tied > searched ? Kmax : 4;
+      ties_seen = st.spec_ties;
     }
     if (st.cursor == done && st.status == 0) FAIL(ctx, FVDB_E_HIP, "device insert made no progress");
     done = st.cursor;

@@ -42,12 +42,18 @@ namespace fvdb {
 
 constexpr int kBuildWaves = 8;                   // wavefronts per workgroup
 constexpr int kBuildThreads = kBuildWaves * 64;
-constexpr int kSpec = 16;                        // candidates whose lists are wanted on chip each round
+#ifndef FVDB_BUILD_SPEC
+#define FVDB_BUILD_SPEC 16
+#endif
+constexpr int kSpec = FVDB_BUILD_SPEC;           // candidates whose lists are wanted on chip each round
 constexpr int kSlots = 32;                       // scored adjacency lists the table holds (>= 2 kSpec)
 constexpr int kBuildLayers = 16;                 // layers of one node handled on chip (level <= 15: p = 0.408^16 otherwise)
 constexpr int kNearRegs = 4;                     // sorted `nearest`: 4 registers x 64 lanes => ef <= 256
 constexpr uint32_t kResWords = 2 + 2 * 64;       // per layer: count, pad, 64 nodes, 64 distances
-constexpr uint32_t kSpecWords = 8 + kBuildLayers * kResWords;  // one speculated insert in HBM
+// one speculated insert in HBM: 64 header words — [1] node, [2] the entry point it started from, [8 + l] the batch tag if
+// layer l's search is usable, [24 + l] expanded rows logged by layer l's search — then the layers' results
+constexpr uint32_t kSpecHdr = 64;
+constexpr uint32_t kSpecWords = kSpecHdr + kBuildLayers * kResWords;
 constexpr uint32_t kLogCap = 2048;               // expanded rows remembered per speculated insert
 constexpr uint32_t kTileRows = 16;               // rows of a wave's product tile
 
@@ -58,7 +64,8 @@ struct BuildState {
   uint32_t status;                                   // 0 ok; 1: node `cursor` needs the host path (on-chip heap overflow)
   uint32_t n_valid, n_rerun, n_stopped;              // speculation statistics
   uint32_t rounds, consumed, scored, ties;           // search statistics (sums)
-  uint32_t pad[3];
+  uint32_t spec_ties;                                // speculated searches that met equal distances
+  uint32_t pad[2];
 };
 
 struct BuildView {
@@ -765,11 +772,9 @@ __device__ __forceinline__ bool ef_search(const BuildView& g, BuildCtx& c, const
   const uint32_t log0 = c.misc[MS_NLOG];
   if (g.ef <= (uint32_t)kNearRegs * 64u) {
     if (ef_search_layer<NB, FULL, false>(g, c, q2, layer, start, start_d, elog, stat)) return true;
+    if (threadIdx.x == 0 && stat) stat[3] += 1;
     if (!exact_on_tie) return false;  // a speculation far down the batch: not worth twice the time of the others
-    if (threadIdx.x == 0) {
-      c.misc[MS_NLOG] = log0;  // the aborted attempt expanded a prefix of what the exact run expands
-      if (stat) stat[3] += 1;
-    }
+    if (threadIdx.x == 0) c.misc[MS_NLOG] = log0;  // the aborted attempt expanded a prefix of what the exact run expands
     __syncthreads();
   }
   return ef_search_layer<NB, FULL, true>(g, c, q2, layer, start, start_d, elog, stat);
@@ -784,7 +789,8 @@ __device__ __forceinline__ bool ef_search(const BuildView& g, BuildCtx& c, const
 // ---------------------------------------------------------------------------------------------
 template <int NB, bool FULL>
 __device__ __forceinline__ bool insert_searches(const BuildView& g, BuildCtx& c, uint32_t node, uint32_t level, uint32_t entry,
-                                                uint32_t entry_level, uint32_t* elog, uint32_t* stat, bool exact_on_tie = true) {
+                                                uint32_t entry_level, uint32_t* elog, uint32_t* stat, bool exact_on_tie = true,
+                                                int only_layer = -1 /* >= 0: the descent + that layer's search only */) {
   float2 q2[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -807,10 +813,13 @@ __device__ __forceinline__ bool insert_searches(const BuildView& g, BuildCtx& c,
   float cur_d = entry_d;
   const uint32_t search_level = min(level, entry_level);
   BSTAMP(tg0);
-  for (uint32_t lc = search_level + 1; lc-- > 0;) greedy_layer<NB, FULL>(g, c, q2, lc, cur, cur_d, elog);
+  // the descent's expansions are logged once per insert: by the whole-insert call, or by the layer-0 call
+  if (only_layer < 0 || (uint32_t)only_layer <= search_level)
+    for (uint32_t lc = search_level + 1; lc-- > 0;) greedy_layer<NB, FULL>(g, c, q2, lc, cur, cur_d, only_layer <= 0 ? elog : nullptr);
   BSTAMP(tg1);
   BSTAMP_ADD(g, 3, tg0, tg1);
   for (uint32_t lc = 0; lc <= level; ++lc) {
+    if (only_layer >= 0 && lc != (uint32_t)only_layer) continue;
     const bool low = lc <= search_level;
     if (!ef_search<NB, FULL>(g, c, q2, lc, low ? cur : entry, low ? cur_d : entry_d, elog, stat, exact_on_tie)) return false;
   }
@@ -884,42 +893,41 @@ __device__ __forceinline__ void insert_links(const BuildView& g, BuildCtx& c, ui
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-// Speculation: workgroup b searches for node first + cursor + b against the graph as it stands.
+// Speculation: workgroup (b, l) runs the layer-l search of node first + cursor + b against the graph as it stands (the
+// searches of an insert's layers only share the greedy descent, which every one of them repeats: a node with levels
+// would otherwise take several times as long as its batch mates, and the slowest workgroup sets the launch's duration).
 template <int NB, bool FULL>
-__global__ __launch_bounds__(kBuildThreads, 1) void hnsw_insert_search_kernel(const BuildView g, uint32_t first, uint32_t n,
-                                                                              uint32_t* __restrict__ spec /* [grid][kSpecWords] */,
-                                                                              uint32_t* __restrict__ elogs /* [grid][kLogCap] */) {
+__global__ __launch_bounds__(kBuildThreads, 1) void hnsw_insert_search_kernel(const BuildView g, uint32_t first, uint32_t n, uint32_t exact_positions,
+                                                                              uint32_t tag, uint32_t* __restrict__ spec /* [grid.x][kSpecWords] */,
+                                                                              uint32_t* __restrict__ elogs /* [grid.x][kBuildLayers][kLogCap] */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_b[];
-  const BuildLds L = build_lds_layout(g.bitmap_words, g.ef, g.cand_cap);
-  BuildCtx c = build_ctx(lds_b, L);
+  const uint32_t layer = blockIdx.y;
   const BuildState st = *g.state;
   const uint32_t idx = st.cursor + blockIdx.x;
-  uint32_t* out = spec + (size_t)blockIdx.x * kSpecWords;
-  if (idx >= n || st.status != 0) {
-    if (threadIdx.x == 0) out[0] = 0;  // nothing speculated
-    return;
-  }
+  if (idx >= n || st.status != 0 || !st.has_entry) return;  // the flags in the header keep an older batch's tag: not usable
   const uint32_t node = first + idx;
   const uint32_t level = g.level[node];
-  if (!st.has_entry || level >= (uint32_t)kBuildLayers) {
-    if (threadIdx.x == 0) out[0] = 0;
-    return;
-  }
-  uint32_t* elog = elogs + (size_t)blockIdx.x * kLogCap;
+  if (level >= (uint32_t)kBuildLayers || layer > level) return;
+  const BuildLds L = build_lds_layout(g.bitmap_words, g.ef, g.cand_cap);
+  BuildCtx c = build_ctx(lds_b, L);
+  uint32_t* out = spec + (size_t)blockIdx.x * kSpecWords;
+  uint32_t* elog = elogs + ((size_t)blockIdx.x * kBuildLayers + layer) * kLogCap;
   // a search that meets equal distances starts again with the restated heaps — twice the time: only the first few
   // speculations of a batch, the ones most likely to be adopted, do that; the others are left to the next batch
-  const bool ok = insert_searches<NB, FULL>(g, c, node, level, st.entry, st.entry_level, elog, nullptr, blockIdx.x < 4);
+  // (`exact_positions`: the host raises it to the whole batch on data where ties are the rule, e.g. duplicate vectors)
+  uint32_t tstat[4] = {0, 0, 0, 0};
+  const bool ok = insert_searches<NB, FULL>(g, c, node, level, st.entry, st.entry_level, elog, tstat, blockIdx.x < exact_positions, (int)layer);
   __syncthreads();
-  // header: [0] 1 = usable, [1] node, [2] entry it started from, [3] expanded rows logged
   const uint32_t nlog = c.misc[MS_NLOG];
   if (threadIdx.x == 0) {
-    out[0] = (ok && nlog <= kLogCap) ? 1u : 0u;
+    if (tstat[3] || !ok) atomicAdd(&g.state->spec_ties, 1u);
     out[1] = node;
     out[2] = st.entry;
-    out[3] = nlog;
+    out[8 + layer] = (ok && nlog <= kLogCap) ? tag : 0u;
+    out[24 + layer] = nlog;
   }
-  const uint32_t words = (level + 1) * kResWords;
-  for (uint32_t i = threadIdx.x; i < words; i += kBuildThreads) out[8 + i] = c.res[i];
+  const uint32_t* r = c.res + layer * kResWords;
+  for (uint32_t i = threadIdx.x; i < kResWords; i += kBuildThreads) out[kSpecHdr + layer * kResWords + i] = r[i];
 }
 
 // Commit: ONE workgroup takes the nodes first + cursor ... in order.  A speculated search is adopted when every row it
@@ -965,23 +973,27 @@ __global__ __launch_bounds__(kBuildThreads, 1) void hnsw_insert_commit_kernel(co
     bool have = false;
     if (spec) {
       const uint32_t* sp = spec + (size_t)b * kSpecWords;
-      if (sp[0] == 1 && sp[1] == node && sp[2] == st.entry) {
+      bool usable = sp[1] == node && sp[2] == st.entry;
+      for (uint32_t l = 0; l <= level; ++l) usable = usable && sp[8 + l] == tag;
+      if (usable) {
         if (threadIdx.x == 0) c.misc[MS_CONFLICT] = 0;
         __syncthreads();
-        const uint32_t nlog = sp[3];
-        const uint32_t* el = elogs + (size_t)b * kLogCap;
         bool bad = false;
-        for (uint32_t i = threadIdx.x; i < nlog; i += kBuildThreads) {
-          const uint32_t code = el[i];
-          const uint32_t s = (code >> 31) ? g.stampU[code & 0x7FFFFFFFu] : g.stamp0[code];
-          bad = bad || s == tag;
+        for (uint32_t l = 0; l <= level; ++l) {
+          const uint32_t nlog = sp[24 + l];
+          const uint32_t* el = elogs + ((size_t)b * kBuildLayers + l) * kLogCap;
+          for (uint32_t i = threadIdx.x; i < nlog; i += kBuildThreads) {
+            const uint32_t code = el[i];
+            const uint32_t sv = (code >> 31) ? g.stampU[code & 0x7FFFFFFFu] : g.stamp0[code];
+            bad = bad || sv == tag;
+          }
         }
         if (bad) c.misc[MS_CONFLICT] = 1;
         __syncthreads();
         have = c.misc[MS_CONFLICT] == 0;
         if (have) {
           const uint32_t words = (level + 1) * kResWords;
-          for (uint32_t i = threadIdx.x; i < words; i += kBuildThreads) c.res[i] = sp[8 + i];
+          for (uint32_t i = threadIdx.x; i < words; i += kBuildThreads) c.res[i] = sp[kSpecHdr + i];
         }
         __syncthreads();
       }

@@ -58,7 +58,7 @@ def test_c1_sequential_insert_graph_and_searches_match_oracle(fv, ctx, generator
     gh = fv.HNSWIndex(ctx, 16, 32, 200, seed=42)
     gh.batch_insert(ids, x, levels)
     t2 = time.time()
-    print(f"[c1 {generator}] oracle build {t1 - t0:.1f}s, GPU-scored build {t2 - t1:.1f}s, dist evals {gh.dist_evals()}")
+    print(f"[c1 {generator}] oracle build {t1 - t0:.1f}s, device build {t2 - t1:.1f}s")
     assert gh.node_count() == N and gh.entry_point() == oh.entry_point()
     gi, lv, off, nb = gh.export_graph()
     slot = 0
@@ -74,13 +74,18 @@ def test_c1_sequential_insert_graph_and_searches_match_oracle(fv, ctx, generator
         assert np.array_equal(got.counts, want[2]) and np.array_equal(got.ids, want[0]), device
         assert np.array_equal(bits(got.distances), bits(want[1])), device
     gh.set_device_traversal(True)
-    if generator == "survey_mixture":
-        assert gh.device_fallbacks() == 0
-    else:
-        # ten exact copies of every vector: equal distances everywhere, so every query runs the restated-heap search
-        # and the walks are long; queries that outgrow the on-chip candidate heap / visited log are finished by the
-        # host walk (status 1) — allowed, and the results above are the oracle's either way
-        print(f"[c1 {generator}] queries finished by the host walk: {gh.device_fallbacks()} of {2 * NQ}")
+    # every query finishes on the device on both generators.  The reference bench's data (ten exact copies of every
+    # vector: equal distances everywhere) sends every query through the restated-heap search and makes the walks long;
+    # a query that outgrows its visited log now clears its whole map at the end of the layer instead of leaving the device
+    assert gh.device_fallbacks() == 0
+    st = gh.insert_stats()
+    assert st["host_path_inserts"] == 0 and st["n_done"] == N
+    print(f"[c1 {generator}] device insert: {st}")
+    # build time against the CPU oracle's (single thread, the reference's own cost model).  On the mixture the device
+    # build is the faster one.  The reference bench's generator walks a line — consecutive inserts are each other's
+    # nearest neighbours, so no two inserts of a batch are independent, and every search ties and takes the restated
+    # heaps: that data is built one insert at a time at the latency of ONE workgroup, somewhat behind a CPU core.
+    assert t2 - t1 <= (1.0 if generator == "survey_mixture" else 1.6) * (t1 - t0) + 1.0, (t2 - t1, t1 - t0)
     if generator == "survey_mixture":
         # self-match (tests/hnsw/core.rs:199-226) at this shape: the reference's nearest-M neighbour selection (no
         # diversity heuristic) leaves well-separated components poorly connected, so ef = 50 finds ~70 % of the stored

@@ -45,11 +45,14 @@ def main():
     ap.add_argument("--check", action="store_true", help="build the same graph with the CPU oracle and compare")
     ap.add_argument("--host", action="store_true", help="host algorithm with per-hop GPU scoring instead")
     ap.add_argument("--chunk", type=int, default=0, help="insert in chunks of this many (0 = one batch_insert call)")
+    ap.add_argument("--tail", type=int, default=0, help="after the build: this many more inserts, timed on their own")
+    ap.add_argument("--tail-mode", type=int, default=1)
     a = ap.parse_args()
     fv = fvdb_import.load()
     import oracle as orc
     orc.build()
-    x = gen(a.gen, a.n, a.d, 1234)
+    x = gen(a.gen, a.n + a.tail, a.d, 1234)
+    xt, x = x[a.n:], x[:a.n]
     ids = np.arange(a.n, dtype=np.uint64)
     levels = orc.rng_levels(42, a.n)
     ctx = fv.Context(0)
@@ -66,6 +69,15 @@ def main():
     st = gh.insert_stats()
     print(f"[build] n {a.n} d {a.d} gen {a.gen} mode {a.mode} host {a.host}: {t1 - t0:.2f}s = {a.n / (t1 - t0):.0f} inserts/s "
           f"({(t1 - t0) / a.n * 1e3:.3f} ms each)  stats {st}", flush=True)
+    if a.tail:
+        gh.set_device_insert(not a.host, a.tail_mode)
+        b = gh.insert_stats()
+        t0 = time.time()
+        gh.batch_insert(np.arange(a.n, a.n + a.tail, dtype=np.uint64), xt, orc.rng_levels(43, a.tail))
+        t1 = time.time()
+        e = gh.insert_stats()
+        print(f"[tail] {a.tail} inserts at {a.n} nodes, mode {a.tail_mode}: {(t1 - t0) / a.tail * 1e3:.3f} ms each; "
+              f"{ {k: e[k] - b[k] for k in e} }", flush=True)
     if a.check:
         t0 = time.time()
         oh = orc.HNSWIndex(a.m, a.m0, a.efc, seed=42)
