@@ -65,6 +65,7 @@ SIGNATURES = {
     "fvdb_ivf_coarse_fallbacks": (i32, [vp, u64p]),
     "fvdb_ivf_set_scan_mode": (i32, [vp, i32]),
     "fvdb_ivf_scan_fallbacks": (i32, [vp, u64p]),
+    "fvdb_ivf_scan_fallback_reasons": (i32, [vp, u64p]),
     "fvdb_ivf_scan_survivors": (i32, [vp, u32p, u32]),
     "fvdb_ivf_scan_survivor_dump": (i32, [vp, u32, u32, u32p, u32p, f32p, u32p]),
     "fvdb_ivf_last_stats": (i32, [vp, C.POINTER(SearchStats)]),

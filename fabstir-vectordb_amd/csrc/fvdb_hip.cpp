@@ -128,12 +128,12 @@ struct IvfScratch {
   bool pend_filter = false;
   bool pending_profile = false, pend_coarse = false, pend_fine = false, collecting = false;
   DBuf s_qnorm, s_A;
-  DBuf s_qh, s_qn2, s_thr, s_tA, s_pa, s_surv, s_scnt, s_fail, s_mslots, s_sdist;
+  DBuf s_qh, s_qn2, s_thr, s_tA, s_pa, s_surv, s_scnt, s_fail, s_mslots, s_sdist, s_probes2;
   DBuf s_q, s_cpart, s_probes, s_cnt, s_fill, s_eoff, s_ioff, s_entries, s_part, s_scalars, s_ceoff, s_cioff;
   DBuf s_in, s_slots, s_ids, s_clusters, s_out_ids, s_out_dist, s_out_cnt, s_cdist;
   hipEvent_t sev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   void release_all() {
-    DBuf* bufs[] = {&s_qnorm, &s_A, &s_qh, &s_qn2, &s_thr, &s_tA, &s_pa, &s_surv, &s_scnt, &s_fail, &s_mslots, &s_sdist,
+    DBuf* bufs[] = {&s_qnorm, &s_A, &s_qh, &s_qn2, &s_thr, &s_tA, &s_pa, &s_surv, &s_scnt, &s_fail, &s_mslots, &s_sdist, &s_probes2,
                     &s_q, &s_cpart, &s_probes, &s_cnt, &s_fill, &s_eoff, &s_ioff, &s_entries, &s_part, &s_scalars,
                     &s_ceoff, &s_cioff, &s_in, &s_slots, &s_ids, &s_clusters, &s_out_ids, &s_out_dist, &s_out_cnt, &s_cdist};
     for (DBuf* b : bufs) b->release();
@@ -172,11 +172,15 @@ struct fvdb_ivf : IvfScratch {
   // AUTO scan mode watches its own hit rate: the rescan counter is copied to pinned host memory behind every
   // matrix-core batch (no sync); when too many queries of the recent batches needed the exact rescan (data the
   // filter cannot separate, e.g. no cluster structure), the next batches go straight to the exact scan
-  HBuf h_fb;                 // pinned copy of s_fallbacks[1]
+  HBuf h_fb;                 // pinned copy of s_fallbacks[0..7]
   uint64_t mfma_q = 0;       // queries sent down the matrix-core path
   uint64_t fb_seen = 0, q_seen = 0;  // counter / queries at the last decision
   uint32_t exact_batches_left = 0;   // > 0: AUTO is backing off to the exact scan
   uint32_t backoff_len = 0;
+  // the second filter pass for queries whose survivors outgrew the buffer (refine_threshold_kernel) costs five small
+  // launches per batch: AUTO enqueues them only while such queries have been seen recently (counters [2] and [6])
+  uint64_t overflow_seen = 0;
+  uint32_t refine_batches_left = 0;
   DBuf d_xmax;           // max |x|^2 over the rows ever added (float bits)
   Pool cpool;
   DBuf c_off, c_blocks, c_glob;  // single-list table for the centroid pool
@@ -685,6 +689,39 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
     a.stamps = nullptr;
   }
   if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[7], ctx->stream);
+  // B'. queries whose survivors outgrew the buffer get a threshold from those survivors and a second filter pass over
+  //     their probes alone (normally nobody: the three plan kernels and the filter find nothing to do)
+  static const bool no_refine = getenv("FVDB_MFMA_NO_REFINE") != nullptr;  // tuning aid / A-B
+  bool refine = !E.given_thr && !no_refine;
+  if (refine && ivf->scan_mode == FVDB_SCAN_AUTO) {
+    std::lock_guard<std::mutex> lk(ivf->mu);
+    if (ivf->h_fb.p) {
+      const volatile uint32_t* c = (const volatile uint32_t*)ivf->h_fb.p;
+      const uint64_t now = (uint64_t)c[2] + c[6];
+      if (now != ivf->overflow_seen) {
+        ivf->overflow_seen = now;
+        ivf->refine_batches_left = 1024;
+      }
+    }
+    if (ivf->refine_batches_left > 0) ivf->refine_batches_left -= 1;
+    else refine = false;
+  }
+  if (refine) {
+    HIPCHK(ctx, S.s_probes2.ensure((size_t)B * np * 4));
+    hipLaunchKernelGGL(refine_threshold_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, S.s_sdist.as<float>(),
+                       S.s_scnt.as<uint32_t>(), probes, S.s_qn2.as<float>(), ivf->d_xmax.as<uint32_t>(), B, np, ka, cmax, ivf->dpad,
+                       x_rounded, S.s_thr.as<float>(), S.s_probes2.as<uint32_t>(), ivf->s_fallbacks.as<uint32_t>() + 6);
+    plan(S.s_probes2.as<uint32_t>(), B * np, np, segb, nullptr, a.lsplit, a.segb_tail);
+    if (use_wg) {
+      const dim3 wg_grid((uint32_t)ctx->num_cus * (uint32_t)std::max(1, wg_wgs_env));
+      if (M == 4)
+        hipLaunchKernelGGL(scan_mfma_wg_kernel<4>, wg_grid, dim3(256), mfma_wg_lds_bytes(ivf->dpad, 64), ctx->stream, a);
+      else
+        hipLaunchKernelGGL(scan_mfma_wg_kernel<2>, wg_grid, dim3(256), mfma_wg_lds_bytes(ivf->dpad, 32), ctx->stream, a);
+    } else {
+      launch_mfma<0>(ctx, a, M, half_rows, grid);
+    }
+  }
   if (ivf->ctx->profiling) (void)hipEventRecord(S.sev[4], ctx->stream);
   S.pend_filter = true;
 
@@ -716,6 +753,7 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   v.out_counts = out_counts;
   v.out_keys = out_keys;
   v.fallbacks = ivf->s_fallbacks.as<uint32_t>() + 1;
+  v.reasons = ivf->s_fallbacks.as<uint32_t>() + 2;
   v.fail_list = S.s_fail.as<uint32_t>();
   v.nfail = S.s_scnt.as<uint32_t>() + B;
   if (ivf->f16) hipLaunchKernelGGL((select_kernel<1>), dim3(cdiv(B, 4)), dim3(256), 0, ctx->stream, v);
@@ -760,10 +798,12 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   // the rescan counter, for AUTO's hit-rate watch (run_fine): a 4-byte copy into pinned memory, nobody waits for it
   {
     std::lock_guard<std::mutex> lk(ivf->mu);
+    const bool fresh = ivf->h_fb.p == nullptr;
     HIPCHK(ctx, ivf->h_fb.ensure(64));
+    if (fresh) std::memset(ivf->h_fb.p, 0, 64);
     ivf->mfma_q += B;
   }
-  HIPCHK(ctx, hipMemcpyAsync(ivf->h_fb.p, ivf->s_fallbacks.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ivf->h_fb.p, ivf->s_fallbacks.p, 32, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipGetLastError());
   return FVDB_OK;
 }
@@ -773,16 +813,16 @@ int run_fine(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, uint32_
   IvfScratch& S = *E.S;
   static const bool env_exact = getenv("FVDB_SCAN_EXACT") != nullptr;  // tuning aid
   S.pend_filter = false;
-  bool mfma = ivf->scan_mode == 0 && !env_exact && role == ROLE_LIST && ivf->dpad % 16 == 0 &&
+  bool mfma = (ivf->scan_mode == FVDB_SCAN_AUTO || ivf->scan_mode == FVDB_SCAN_FILTER) && !env_exact && role == ROLE_LIST && ivf->dpad % 16 == 0 &&
               k + kMfmaSlack <= 32 && np <= 256 && B >= 32 && B <= 16384 && ivf->pool.norms != nullptr;
-  if (mfma) {
+  if (mfma && ivf->scan_mode == FVDB_SCAN_AUTO) {
     std::lock_guard<std::mutex> lk(ivf->mu);  // the hit-rate watch is shared by every search on the index
     if (ivf->exact_batches_left > 0) {
       ivf->exact_batches_left -= 1;
       mfma = false;
     } else if (ivf->h_fb.p && ivf->mfma_q - ivf->q_seen >= 2048) {
       // rescans among the matrix-core queries since the last look (the counter lags by the batches in flight)
-      const uint64_t fb_now = *(volatile uint32_t*)ivf->h_fb.p;
+      const uint64_t fb_now = ((volatile uint32_t*)ivf->h_fb.p)[1];
       const uint64_t dq = ivf->mfma_q - ivf->q_seen, dfb = fb_now - ivf->fb_seen;
       ivf->q_seen = ivf->mfma_q;
       ivf->fb_seen = fb_now;
@@ -1214,15 +1254,17 @@ static int install_centroids(fvdb_ivf* ivf, const float* d_rowmajor /* device [n
   }
   HIPCHK(ctx, ivf->d_cnorm.ensure((size_t)nlist * 4));
   HIPCHK(ctx, ivf->d_cnmax.ensure(4));
-  HIPCHK(ctx, ivf->s_fallbacks.ensure(8));  // [0] coarse, [1] list scan
+  HIPCHK(ctx, ivf->s_fallbacks.ensure(32));  // [0] coarse, [1] list scan, [2..5] why a query was not proven (VerifyArgs::reasons)
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(nlist, 256)), dim3(256), 0, ctx->stream, cpad, ivf->dpad, ivf->dpad,
                      nlist, ivf->d_cnorm.as<float>());
   hipLaunchKernelGGL(max_f32_kernel, dim3(1), dim3(64), 0, ctx->stream, ivf->d_cnorm.as<float>(), nlist,
                      ivf->d_cnmax.as<float>());
-  HIPCHK(ctx, hipMemsetAsync(ivf->s_fallbacks.p, 0, 8, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ivf->s_fallbacks.p, 0, 32, ctx->stream));
   if (ivf->h_fb.p) *(volatile uint32_t*)ivf->h_fb.p = 0;
   ivf->mfma_q = ivf->fb_seen = ivf->q_seen = 0;
   ivf->exact_batches_left = ivf->backoff_len = 0;
+  ivf->overflow_seen = 0;
+  ivf->refine_batches_left = 0;
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ivf->trained = true;
@@ -1742,7 +1784,7 @@ int fvdb_ivf_set_coarse_mode(fvdb_ivf* ivf, int mode) {
 
 int fvdb_ivf_set_scan_mode(fvdb_ivf* ivf, int mode) {
   if (!ivf) return FVDB_E_INVALID;
-  if (mode != FVDB_SCAN_AUTO && mode != FVDB_SCAN_EXACT) FAIL(ivf->ctx, FVDB_E_INVALID, "unknown scan mode");
+  if (mode != FVDB_SCAN_AUTO && mode != FVDB_SCAN_EXACT && mode != FVDB_SCAN_FILTER) FAIL(ivf->ctx, FVDB_E_INVALID, "unknown scan mode");
   ivf->scan_mode = mode;
   return FVDB_OK;
 }
@@ -1803,6 +1845,18 @@ int fvdb_ivf_scan_fallbacks(fvdb_ivf* ivf, uint64_t* out) {
   HIPCHK(ctx, hipMemcpyAsync(&v, ivf->s_fallbacks.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   *out = v;
+  return FVDB_OK;
+}
+
+int fvdb_ivf_scan_fallback_reasons(fvdb_ivf* ivf, uint64_t* out5) {
+  fvdb_ctx* ctx = ivf->ctx;
+  for (int i = 0; i < 5; ++i) out5[i] = 0;
+  if (!ivf->s_fallbacks.p) return FVDB_OK;
+  uint32_t v[5] = {0, 0, 0, 0, 0};
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpyAsync(v, ivf->s_fallbacks.as<uint32_t>() + 2, 20, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 5; ++i) out5[i] = v[i];
   return FVDB_OK;
 }
 

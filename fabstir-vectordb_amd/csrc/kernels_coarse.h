@@ -14,6 +14,7 @@
 #pragma once
 #include "common.h"
 #include "kernels_scan.h"
+#include "score_rows.h"
 
 #pragma clang fp contract(off)
 
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restr
                                                             uint32_t kc, uint32_t* __restrict__ out_probes,
                                                             float* __restrict__ out_dist,
                                                             uint32_t* __restrict__ n_exact_fallbacks) {
+  __shared__ __attribute__((aligned(16))) float s_tile[4][kScoreTileFloats];  // product tiles (score_rows.h)
   const int lane = threadIdx.x & 63;
   const uint32_t b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));  // wave-uniform
   if (b >= B) return;
@@ -149,11 +151,14 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restr
   }
   const bool all_in = C >= nlist;  // every centroid is a candidate: nothing to prove
   // 2. the reference's distance for the candidates
+  // (the whole wave scores them: coalesced loads, products through an LDS tile, per-lane sequential sums — score_rows.h)
   uint32_t ehi = kInf32, elo = kInf32;
-  if ((uint32_t)lane < C && prop.hi[0] != kInf32) {
-    const uint32_t cid = prop.lo[0];
-    ehi = __float_as_uint(exact_centroid_dist(qrow, c + (size_t)cid * dpad, dpad));
-    elo = cid;
+  const bool cand = (uint32_t)lane < C && prop.hi[0] != kInf32;
+  const uint32_t ncand = __popcll(__ballot(cand));  // the proposals are sorted: the valid ones are lanes 0 .. ncand-1
+  const float dex = score_rows_wave(c, dpad, qrow, cand ? prop.lo[0] : 0u, ncand, s_tile[threadIdx.x >> 6], lane);
+  if (cand) {
+    ehi = __float_as_uint(dex);
+    elo = prop.lo[0];
   }
   wave_sort64(ehi, elo, lane);  // ascending (distance, cluster id) = the reference's stable sort order
   // 3. can a centroid outside the candidates reach the top kc?  |approx - reference sum| <= 2 eps, where

@@ -26,6 +26,7 @@
 // instruction scores 64 rows x 16 queries x 8 dims with no LDS transposition, at half the MFMA rate — which
 // still leaves the kernel bound by the row stream from L2/HBM, not by arithmetic.
 #pragma once
+#include "score_rows.h"
 #include "common.h"
 #include "kernels_scan.h"
 
@@ -747,6 +748,56 @@ __global__ void fill_f32_kernel(float* __restrict__ p, uint32_t n, float v) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// B'. refine: a query whose survivors outgrew the buffer had a loose threshold (the sampled list did not hold its near
+// rows).  The cmax survivors that were stored are actual live rows, so the ka-th smallest v among them is a valid a_q,
+// and a far tighter one: the query gets thr = a' + 2 E, an empty survivor buffer and its probes back in probes2[] — the
+// filter runs once more over probes2[] (everybody else's row there is all "no list": no work).  One wave per query.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void refine_threshold_kernel(const float* __restrict__ sval, uint32_t* __restrict__ scnt,
+                                                               const uint32_t* __restrict__ probes, const float* __restrict__ qn,
+                                                               const uint32_t* __restrict__ xmax_bits, uint32_t B, uint32_t np,
+                                                               uint32_t ka, uint32_t cmax, uint32_t d, int rows_f16,
+                                                               float* __restrict__ thr, uint32_t* __restrict__ probes2,
+                                                               uint32_t* __restrict__ n_refined) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t q = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (q >= B) return;
+  const float inf = __builtin_huge_valf();
+  bool again = false;
+  if (scnt[q] > cmax) {
+    WaveTopK<1> ta;
+    ta.init();
+    uint32_t th = kInf32, tl = kInf32;
+    for (uint32_t s0 = 0; s0 < cmax; s0 += 64) {
+      const uint32_t s = s0 + lane;
+      uint32_t chi = fmap_u32(sval[(size_t)q * cmax + s]), clo = s;
+      if (s0 == 0) {
+        wave_sort64(chi, clo, lane);
+        ta.hi[0] = chi;
+        ta.lo[0] = clo;
+        ta.kth(ka, th, tl);
+      } else {
+        offer<1>(ta, ka, chi, clo, th, tl, lane);
+      }
+    }
+    const float E = mfma_error_bound(__uint_as_float(*xmax_bits), qn[q], (float)d, rows_f16);
+    if (th != kInf32 && th != 0u && E < inf) {
+      const float a = funmap_u32(th);
+      const float t2 = a + 2.0f * E + 1e-6f * fabsf(a);
+      if (t2 < thr[q]) {
+        again = true;
+        if (lane == 0) {
+          thr[q] = t2;
+          scnt[q] = 0;
+          if (n_refined) atomicAdd(n_refined, 1u);
+        }
+      }
+    }
+  }
+  for (uint32_t r = lane; r < np; r += 64) probes2[(size_t)q * np + r] = again ? probes[(size_t)q * np + r] : kInf32;
+}
+
+// ---------------------------------------------------------------------------------------------
 // C. select
 // ---------------------------------------------------------------------------------------------
 struct VerifyArgs {
@@ -772,14 +823,19 @@ struct VerifyArgs {
   uint32_t* out_counts;
   uint64_t* out_keys;
   uint32_t* fallbacks;   // running counter of queries that were not proven
+  uint32_t* reasons;     // [4] of those: survivor buffer overflow, too many candidates for one pass set, the k-th kept
+                         // distance not strictly below the bound, no usable threshold
   uint32_t* fail_list;   // [B] queries of this batch to be rescanned exactly (fallback_scan_kernel)
   uint32_t* nfail;       // device scalar, zeroed per batch
 };
 
+constexpr uint32_t kSelCand = 256;  // candidates the select stage scores with the reference's fold (four sets of 64)
+
 template <int ST>
 __global__ __launch_bounds__(256) void select_kernel(const VerifyArgs m) {
   __shared__ uint32_t s_base[4][256];  // scan-order base (in rows) of each probe rank, per wave
-  __shared__ uint32_t s_cand[4][64];   // survivor indices to score
+  __shared__ uint32_t s_cand[4][kSelCand];  // survivor indices to score
+  __shared__ __attribute__((aligned(16))) float s_tile[4][kScoreTileFloats];  // product tiles (score_rows.h)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t q = rfl(blockIdx.x * 4 + w);
   if (q >= m.B) return;
@@ -838,47 +894,82 @@ __global__ __launch_bounds__(256) void select_kernel(const VerifyArgs m) {
     // for "every unscored row has v > cut" (a' <= a_q makes this a no-op unless the two passes rounded differently)
     cut = fminf(cut, m.thr[q]);
   }
+  uint32_t reason = proven ? 0u : 1u;  // 1: the survivor buffer overflowed
   uint32_t ncand = 0;
   if (proven) {
-    for (uint32_t s0 = 0; s0 < cnt && ncand <= 64; s0 += 64) {
+    for (uint32_t s0 = 0; s0 < cnt && ncand <= kSelCand; s0 += 64) {
       const uint32_t s = s0 + lane;
       const bool c = s < cnt && !(m.sval[(size_t)q * m.cmax + s] > cut);
       const uint64_t mask = __ballot(c);
       const uint32_t slot = ncand + __popcll(mask & ((1ull << lane) - 1ull));
-      if (c && slot < 64) s_cand[w][slot] = s;
+      if (c && slot < kSelCand) s_cand[w][slot] = s;
       ncand += __popcll(mask);
     }
-    if (ncand > 64) proven = false;
+    if (ncand > kSelCand) {
+      proven = false;
+      reason = 2;
+    }
   }
   uint32_t khi = kInf32, klo = kInf32;
   if (proven) {
-    if ((uint32_t)lane < ncand) {
-      const u32x2 sv = m.surv[(size_t)q * m.cmax + s_cand[w][lane]];
-      const uint32_t L = m.probes[(size_t)q * np + sv.x];
-      const uint32_t blk = m.lists.blocks[m.lists.off[L] + (sv.y >> 6)];
-      const float* qrow = m.queries + (size_t)q * m.dpad;
-      khi = __float_as_uint(ST == 0 && m.rows_rm
-                                ? exact_row_dist_rm(m.rows_rm + ((size_t)blk * 64 + (sv.y & 63)) * m.dpad, m.pool.d4, qrow)
-                                : exact_row_dist<ST>(m.pool.data, m.pool.d4, blk, (int)(sv.y & 63), qrow));
-      klo = s_base[w][sv.x] + sv.y;
+    // the candidates are scored 64 at a time (16 rows per pass of the wave, score_rows.h); the min(k, 64) best keys are
+    // kept across the sets in a wave-distributed sorted list
+    const float* qrow = m.queries + (size_t)q * m.dpad;
+    WaveTopK<1> best;
+    best.init();
+    uint32_t bh = kInf32, bl = kInf32;
+    const uint32_t keep = min(m.k, 64u);
+    for (uint32_t c0 = 0; c0 < ncand || c0 == 0; c0 += 64) {
+      const uint32_t nset = min(64u, ncand - c0);
+      u32x2 sv = {0u, 0u};
+      uint32_t blk = 0, chi = kInf32, clo = kInf32;
+      if ((uint32_t)lane < nset) {
+        sv = m.surv[(size_t)q * m.cmax + s_cand[w][c0 + lane]];
+        const uint32_t L = m.probes[(size_t)q * np + sv.x];
+        blk = m.lists.blocks[m.lists.off[L] + (sv.y >> 6)];
+        clo = s_base[w][sv.x] + sv.y;
+      }
+      if (nset > 0) {
+        if (ST == 0 && m.rows_rm) {
+          // rows from the row-major copy, scored by the whole wave: coalesced loads, products through an LDS tile, per-lane
+          // sequential sums — one memory latency per 16 rows where each lane walking its own 1.5 KB row took ~25 dependent ones
+          const float dsel = score_rows_wave(m.rows_rm, m.dpad, qrow, blk * 64u + (sv.y & 63u), nset, s_tile[w], lane);
+          if ((uint32_t)lane < nset) chi = __float_as_uint(dsel);
+        } else if ((uint32_t)lane < nset) {
+          chi = __float_as_uint(exact_row_dist<ST>(m.pool.data, m.pool.d4, blk, (int)(sv.y & 63), qrow));
+        }
+      }
+      if (c0 == 0) {
+        wave_sort64(chi, clo, lane);
+        best.hi[0] = chi;
+        best.lo[0] = clo;
+        best.kth(keep, bh, bl);
+      } else {
+        offer<1>(best, keep, chi, clo, bh, bl, lane);
+      }
+      if (ncand == 0) break;
     }
-    wave_sort64(khi, klo, lane);
+    khi = best.hi[0];
+    klo = best.lo[0];
     // Rows not scored: filtered out in B (v > thr >= cut) or pruned here (v > cut).  Their reference sums exceed
     // S = cut - E + |q|^2 (>= a' + |q|^2 + E), so their distances are >= sqrt(S): the k-th kept must be strictly
     // below.  cut == +inf means every live probed row was scored: nothing to prove.
     if (cut < inf) {
       const float S = ((cut - E) + m.qn[q]) * 0.999999f;
-      const uint32_t dk = rlane(khi, min(m.k, 64u) - 1);
+      const uint32_t dk = rlane(khi, keep - 1);
       proven = dk != kInf32 && S > 0.0f && __uint_as_float(dk) < sqrtf(S);
+      if (!proven) reason = 3;
     } else {
       // a finite threshold from this device's own rows leaves >= ka survivors; fewer means something is off
       proven = m.remote_thr || m.thr[q] == inf;
+      if (!proven) reason = 4;
     }
   }
   if (!proven) {  // hand the query to the exact rescan (fallback_scan_kernel + merge over the fail list)
     if (lane == 0) {
       m.fail_list[atomicAdd(m.nfail, 1u)] = q;
       if (m.fallbacks) atomicAdd(m.fallbacks, 1u);
+      if (m.reasons && reason) atomicAdd(m.reasons + (reason - 1), 1u);
     }
     return;
   }

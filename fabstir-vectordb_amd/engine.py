@@ -377,6 +377,11 @@ class DeviceIVF:
         self.ctx.check(self.lib.fvdb_ivf_scan_fallbacks(self.h, C.byref(v)))
         return int(v.value)
 
+    def scan_fallback_reasons(self):
+        out = np.zeros(5, np.uint64)
+        self.ctx.check(self.lib.fvdb_ivf_scan_fallback_reasons(self.h, _ptr(out, u64p)))
+        return dict(zip(("survivor_overflow", "too_many_candidates", "bound_not_strict", "no_threshold", "refined"), out.tolist()))
+
     def scan_survivors(self, B):
         out = np.empty(B, np.uint32)
         self.ctx.check(self.lib.fvdb_ivf_scan_survivors(self.h, _ptr(out, u32p), B))

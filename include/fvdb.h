@@ -219,9 +219,14 @@ int fvdb_ivf_coarse_fallbacks(fvdb_ivf* ivf, uint64_t* out);
  * k <= 26, nprobe <= 256 and the batch has 32..16384 queries; other shapes use the exact scan. */
 #define FVDB_SCAN_AUTO 0
 #define FVDB_SCAN_EXACT 1
+#define FVDB_SCAN_FILTER 2 /* the matrix-core filter for every batch it can serve (AUTO without the hit-rate back-off) */
 int fvdb_ivf_set_scan_mode(fvdb_ivf* ivf, int mode);
 /* Queries (since the centroids were installed) that were rescanned exactly. */
 int fvdb_ivf_scan_fallbacks(fvdb_ivf* ivf, uint64_t* out);
+/* of those, by cause: [0] survivor buffer overflow, [1] more candidates than the select stage scores, [2] the k-th kept
+ * distance not strictly below the bound of the unscored rows, [3] no usable threshold; and [4] (not a rescan) queries
+ * whose survivors outgrew the buffer and were filtered a second time with a threshold taken from those survivors */
+int fvdb_ivf_scan_fallback_reasons(fvdb_ivf* ivf, uint64_t* out5);
 
 /* Diagnostic: rows per query that survived the matrix-core filter in the last (sub-)batch of B queries. */
 int fvdb_ivf_scan_survivors(fvdb_ivf* ivf, uint32_t* out, uint32_t B);

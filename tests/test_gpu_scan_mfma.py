@@ -137,8 +137,13 @@ def test_duplicates_tie_at_the_bound(fv, ctx):
     gpu, cpu = build(fv, ctx, x, ids, base[:nlist].copy())
     q = base[:48] + np.float32(0.001)
     run_modes(gpu, cpu, q, 10, 3)
-    # 100 copies: more candidates than one wave scores -> every query must be rescanned exactly
+    # 100 copies: four sets of candidates for the select stage, still no rescan
     x = np.ascontiguousarray(np.repeat(base[:200], 100, axis=0))
+    ids = np.arange(x.shape[0], dtype=np.uint64)
+    gpu, cpu = build(fv, ctx, x, ids, base[:nlist].copy())
+    assert run_modes(gpu, cpu, q, 10, 3) == 0
+    # 300 copies: more candidates than the select stage scores (256) -> every query must be rescanned exactly
+    x = np.ascontiguousarray(np.repeat(base[:100], 300, axis=0))
     ids = np.arange(x.shape[0], dtype=np.uint64)
     gpu, cpu = build(fv, ctx, x, ids, base[:nlist].copy())
     fb = run_modes(gpu, cpu, q, 10, 3)
@@ -206,3 +211,53 @@ def test_matrix_core_values_stay_inside_the_error_bound(fv, ctx, dtype, scale):
         assert np.all(err <= E + 2.0 ** -22 * ref), f"query {b}: max err {err.max():.3e} > bound {E:.3e}"
         checked += rk.size
     assert checked > 500
+
+
+def test_isotropic_survey_generator_has_no_cliff(fv, ctx):
+    # SURVEY §8d's own generator (component means ~ N(0, I_384), rows = mean + 0.35 N(0, I)): in-component distances are
+    # concentrated, several components share a list, and for a good share of the queries the list the threshold is sampled
+    # from does not hold their component — the first filter pass then lets thousands of rows through.  Those queries get a
+    # threshold from their own survivors and a second filter pass (refine_threshold_kernel); nobody is rescanned exactly,
+    # and the answers are the exact scan's and the oracle's bit for bit.
+    d, n_comp, n, nlist, B, k, nprobe = 384, 1024, 160_000, 256, 256, 10, 32
+    rng = np.random.default_rng(77)
+    means = rng.standard_normal((n_comp, d)).astype(np.float32)
+    x = (means[rng.integers(0, n_comp, n)] + np.float32(0.35) * rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+    q = (means[rng.integers(0, n_comp, B)] + np.float32(0.35) * rng.standard_normal((B, d)).astype(np.float32)).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64)
+    ivf = fv.IVFIndex(ctx, n_clusters=nlist, n_probe=nprobe, train_size=40_000, max_iterations=10, seed=3)
+    ivf.train(x[:40_000])
+    ivf.batch_insert(ids, x)
+    h = ivf._dev()
+    import ctypes as C
+    lib = ctx.lib
+
+    def counters():
+        v = C.c_uint64(0)
+        ctx.check(lib.fvdb_ivf_scan_fallbacks(h, C.byref(v)))
+        r = (C.c_uint64 * 5)()
+        ctx.check(lib.fvdb_ivf_scan_fallback_reasons(h, r))
+        return v.value, list(r)
+
+    ctx.check(lib.fvdb_ivf_set_scan_mode(h, 2))  # the filter for every batch, second pass always enqueued
+    f0, r0 = counters()
+    got = ivf.search(q, k, nprobe)
+    f1, r1 = counters()
+    ctx.check(lib.fvdb_ivf_set_scan_mode(h, 1))
+    exact = ivf.search(q, k, nprobe)
+    assert np.array_equal(got.ids, exact.ids) and np.array_equal(bits(got.distances), bits(exact.distances))
+    assert np.array_equal(got.counts, exact.counts)
+    assert f1 - f0 == 0, (f1 - f0, [b - a for a, b in zip(r0, r1)])   # nobody rescanned exactly ...
+    assert r1[4] - r0[4] > 0                                           # ... because the loose ones were refined
+    cpu = orc.IVFIndex(n_clusters=nlist, n_probe=nprobe)
+    cpu.set_trained(ivf.get_centroids())
+    cpu.batch_insert(ids, x)
+    oi, od, oc = cpu.batch_search(q[:48], k, nprobe, threads=4)
+    assert np.array_equal(got.ids[:48], oi) and np.array_equal(bits(got.distances[:48]), bits(od))
+    # AUTO learns it from the counters: after the first batches with overflowing queries the second pass is enqueued
+    ctx.check(lib.fvdb_ivf_set_scan_mode(h, 0))
+    for _ in range(6):
+        auto = ivf.search(q, k, nprobe)
+        assert np.array_equal(auto.ids, exact.ids) and np.array_equal(bits(auto.distances), bits(exact.distances))
+    f2, r2 = counters()
+    assert r2[4] > r1[4]
