@@ -166,6 +166,9 @@ def main():
     ap.add_argument("--allow-hosted", action="store_true",
                     help="multi-GPU: permit the hosted transport (asked for with --transport hosted, or as the fallback when "
                          "RCCL cannot be brought up); without it such a run exits non-zero, so an n_gpus > 1 line is an RCCL line")
+    ap.add_argument("--config", choices=["c3", "c2", "c5"], default="c3",
+                    help="BASELINE.json config: c3 (default) = 1M x 384 hybrid, the headline; c2 = 100K x 384 f32 IVF-flat, nlist 1024, "
+                         "nprobe 32, batch 256; c5 = 1M x 768 rows stored as fp16, IVF-flat, batch 1024")
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--spread", type=float, default=1.5)
     ap.add_argument("--supplementary", action="store_true",
@@ -175,6 +178,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.config != "c3":
+        return run_ivf_config(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # called plainly with --gpus N: start one rank per GPU as a FRESH child process (this process has not touched the
         # GPU and never will), relay its one JSON line, exit with its code
@@ -492,6 +497,7 @@ def main():
                        "recall_held_out_batches": None if held_out is None else round(held_out, 4), "sweep": sweep,
                        "generator": f"gaussian mixture: 4096 comps, means {args.spread}*N(0,I) in a rank-{args.latent} latent space, "
                                     f"unit within-comp sigma, orthonormal embedding into {d}-d + 0.02 ambient noise",
+                       "hw_queues": ctx_ivf.info(),
                        "transport": None if world == 1 and not force_sharded else transport_used,
                        "parallelism": par},
             "roofline": roofline, "cpu_baseline": cpu, "insert_path": ins,
@@ -605,6 +611,144 @@ def cpu_baseline(fv, hyb, x, ids, is_recent, now, q0, gpu_res, k, nprobe, ef, ar
     return {"value": round(ns / tall, 2), "unit": "queries/s", "cores": threads, "kind": "port",
             "sample": f"{ns} queries of the first batch, same index structures and (nprobe, ef); one query per thread",
             "single_thread_value": round(max(8, ns // 8) / t1, 2), "gpu_matches_oracle_on_sample": same}, o
+
+
+def run_ivf_config(args):
+    """BASELINE.json configs[1] (c2) and configs[4] (c5): IVF-flat only, one GPU, the same JSON contract as the headline.
+    A step = one batch through the whole IVF chain (coarse ranking, list scan, selection), queries resident in HBM, up to
+    --in-flight batches enqueued on streams of their own; value = queries / wall time of the timed steps."""
+    import fvdb_import
+    fv = fvdb_import.load()
+    cfg = {"c2": dict(N=100_000, d=384, nlist=1024, nprobe=32, B=256, dtype="f32", train=50_000,
+                      metric="k-NN queries/sec, 100Kx384 f32 IVF-flat nlist=1024 nprobe=32 batch=256 (BASELINE configs[1])",
+                      workload="c2: 100K x 384 f32, IVF-flat nlist 1024 nprobe 32, batch 256, k 10"),
+           "c5": dict(N=1_000_000, d=768, nlist=1024, nprobe=32, B=1024, dtype="f16", train=100_000,
+                      metric="k-NN queries/sec, 1Mx768 fp16 rows IVF-flat nlist=1024 nprobe=32 batch=1024 (BASELINE configs[4])",
+                      workload="c5: 1M x 768 rows stored as fp16, IVF-flat nlist 1024 nprobe 32, batch 1024, k 10")}[args.config]
+    N, d, nlist, nprobe, B, k = cfg["N"], cfg["d"], cfg["nlist"], cfg["nprobe"], cfg["B"], args.k
+    if args.nprobe:
+        nprobe = args.nprobe
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    t0 = time.time()
+    gen = Generator(d=d, latent=args.latent, spread=args.spread)
+    x = np.empty((N, d), np.float32)
+    for c in range(0, N, 10_000):
+        x[c:c + 10_000] = gen.rows(min(10_000, N - c), stream=c // 10_000)
+    ids = np.arange(N, dtype=np.uint64)
+    nb = max(1, min(args.query_batches, 8))
+    queries = [gen.rows(B, stream=10_000_000 + i) for i in range(nb)]
+    ctx = fv.Context(0)
+    ivf = fv.DeviceIVF(ctx, d, nlist, dtype=cfg["dtype"])
+    sample = x[np.random.Generator(np.random.Philox(key=5)).choice(N, cfg["train"], replace=False)]
+    ivf.train(sample, seed=7, max_iterations=25)  # the reference's k-means (src/ivf/core.rs:240-429), 25 iterations
+    ivf.reserve(N)
+    clusters = np.empty(N, np.uint32)
+    for s_ in range(0, N, 100_000):
+        cl, _ = ivf.add(x[s_:s_ + 100_000], ids[s_:s_ + 100_000])
+        clusters[s_:s_ + 100_000] = cl
+    log(f"{args.config}: {N} x {d} ({cfg['dtype']} rows), k-means + insert {time.time() - t0:.1f}s")
+    exact = [ivf.search_all(q, k)[0] for q in queries]
+    depth = max(1, min(args.in_flight, 8))
+    ctxs = [ctx] + [fv.Context(0) for _ in range(depth - 1)]
+    qdev = [ctx.upload(q) for q in queries]
+    outs = [(ctx.alloc(B * k * 8), ctx.alloc(B * k * 4), ctx.alloc(B * 4)) for _ in range(depth)]
+    lib, h = ctx.lib, ivf.h
+
+    def enqueue(i):
+        sl = i % depth
+        o = outs[sl]
+        ctx.check(lib.fvdb_ivf_search_dev_slot(h, ctxs[sl].h if sl else None, sl, qdev[i % nb], B, k, nprobe, o[0], o[1], o[2], None))
+
+    def result(sl):
+        o = outs[sl]
+        return (ctx.download(o[0], (B, k), np.uint64), ctx.download(o[1], (B, k), np.float32), ctx.download(o[2], (B,), np.uint32))
+
+    for i in range(max(args.warmup, depth)):
+        enqueue(i)
+    ctx.device_synchronize()
+    rec = []
+    for i in range(nb):
+        enqueue(i)
+        ctxs[i % depth].synchronize()
+        gi, _, gc = result(i % depth)
+        rec.append(recall_at_k(gi, gc, exact[i], k))
+    recall = float(np.mean(rec))
+    f0 = ivf.scan_fallbacks()
+    ctx.device_synchronize()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        enqueue(i)  # stream-ordered per slot: step i waits for step i - depth on its stream, nobody waits on the host
+    ctx.device_synchronize()
+    elapsed = time.perf_counter() - t1
+    qps = B * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    log(f"{args.steps} steps: {ms_per_step:.3f} ms/step, {qps:.0f} QPS, recall@{k}={recall:.4f}, rescans {ivf.scan_fallbacks() - f0}")
+    # per-stage / per-kernel durations, one batch at a time (HIP events on the launch stream)
+    ctx.set_profiling(1)
+    ivf.stage_times()
+    n_solo = 8
+    for i in range(n_solo):
+        ctx.check(lib.fvdb_ivf_search_dev(h, qdev[i % nb], B, k, nprobe, outs[0][0], outs[0][1], outs[0][2], None))
+    ctx.synchronize()
+    n_prof, stage = ivf.stage_times()
+    ctx.set_profiling(0)
+    st = ivf.last_stats()
+    esz = 2 if (cfg["dtype"] == "f16" or stage.get("mfma_filter_kernel", 0.0) > 0.0) else 4
+    mfma_path = stage.get("mfma_filter_kernel", 0.0) > 0.0
+    scan_ms = (stage["mfma_filter_kernel"] if mfma_path else stage["fine_scan"]) / max(n_prof, 1)
+    phys = st["list_rows_touched"] * d * esz
+    flops = 2.0 * st["rows_scanned"] * d
+    t_b, t_f = phys / (HBM_PEAK_GBPS * 1e9), (flops / (MFMA_F16_PEAK_TFLOPS * 1e12) if mfma_path else 0.0)
+    frac = max(t_b, t_f) / (scan_ms * 1e-3) if scan_ms > 0 else 0.0
+    roofline = {"bound": "hbm" if t_b >= t_f else "mfma", "achieved": round(phys / (scan_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(frac, 4), "traffic": None,
+                "kernel": "fvdb::scan_mfma_wg_kernel (IVF list scan: fp16 MFMA filter over every probed row)" if mfma_path
+                          else "fvdb::scan_topk_kernel (IVF list scan, exact)",
+                "kernel_ms": round(scan_ms, 4), "physical_lower_bound_bytes": int(phys), "useful_flops": int(flops),
+                "algorithmic_bytes_per_launch_survey_8d": int(st["rows_scanned"] * d * (2 if cfg["dtype"] == "f16" else 4)),
+                "rows_scanned_per_query": round(st["rows_scanned"] / B, 1),
+                "stage_ms": {k_: round(v / max(n_prof, 1), 4) for k_, v in stage.items()},
+                "note": "achieved = every probed list streamed once per launch (fp16 rows / fp16 mirror) / the filter kernel's "
+                        "duration (HIP events, one batch at a time); SURVEY 8d's per-query bytes are shared by the queries probing a list"}
+    assert 0.0 <= roofline["frac"] <= 1.0
+    cpu = None
+    if not args.no_cpu_baseline:
+        import oracle as orc
+        orc.build()
+        t2 = time.time()
+        o = orc.IVFIndex(n_clusters=nlist, n_probe=nprobe)
+        o.set_trained(ivf.get_centroids())
+        xo = x.astype(np.float16).astype(np.float32) if cfg["dtype"] == "f16" else x  # the rows the index holds
+        o.batch_insert_assigned(ids, xo, clusters)
+        ns = min(args.cpu_sample, B)
+        threads = usable_cpus()
+        ta = time.perf_counter()
+        o.batch_search(queries[0][: max(8, ns // 8)], k, nprobe, threads=1)
+        t_one = time.perf_counter() - ta
+        ta = time.perf_counter()
+        oi, od, oc = o.batch_search(queries[0][:ns], k, nprobe, threads=threads)
+        t_all = time.perf_counter() - ta
+        enqueue(0)
+        ctxs[0].synchronize()
+        gi, gd, gc = result(0)
+        same = bool(np.array_equal(oc, gc[:ns]) and np.array_equal(oi, gi[:ns]) and np.array_equal(od.view(np.uint32), gd[:ns].view(np.uint32)))
+        log(f"cpu baseline: setup {time.time() - t2:.1f}s; 1 thread {max(8, ns // 8) / t_one:.1f} q/s; {threads} threads {ns / t_all:.1f} q/s; gpu==oracle: {same}")
+        cpu = {"value": round(ns / t_all, 2), "unit": "queries/s", "cores": threads, "kind": "port",
+               "sample": f"{ns} queries of the first batch, same centroids, lists and rows"
+                         + (" (fp16-rounded, as stored)" if cfg["dtype"] == "f16" else "") + "; one query per thread",
+               "single_thread_value": round(max(8, ns // 8) / t_one, 2), "gpu_matches_oracle_on_sample": same}
+    out = {"metric": cfg["metric"], "value": round(qps, 1), "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": cfg["workload"], "n_vectors": N, "dim": d, "batch": B, "k": k, "nlist": nlist, "nprobe": nprobe,
+                      "row_storage": cfg["dtype"], "recall_at_10": round(recall, 4), "batches_in_flight": depth, "query_batches": nb,
+                      "ivf_scan_fallbacks": int(ivf.scan_fallbacks() - f0), "hw_queues": ctx.info(),
+                      "arithmetic": "final distances: the reference's f32 fold over the stored rows; fp16 MFMA only discards rows under a proven bound",
+                      "generator": f"gaussian mixture: 4096 comps in a rank-{args.latent} latent space embedded into {d}-d + 0.02 ambient noise"},
+           "roofline": roofline, "cpu_baseline": cpu}
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 def insert_path(hyb, oracle_hyb, gen, N, n_ins, graph_build_s, args):

@@ -7,7 +7,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("FVDB_HIP_LIB") or os.path.join(_HERE, "lib", "libfvdb_hip.so")  # env: A/B builds
+# FVDB_LIB_DIR: another build of BOTH libraries (lib_dev: the dev build with include/fvdb_dev.h's entry points; A/B builds)
+LIB_DIR = os.environ.get("FVDB_LIB_DIR") or os.path.join(_HERE, "lib")
+if not os.path.isabs(LIB_DIR):
+    LIB_DIR = os.path.join(_HERE, LIB_DIR)
+LIB_PATH = os.environ.get("FVDB_HIP_LIB") or os.path.join(LIB_DIR, "libfvdb_hip.so")
 
 vp, u64, u32, i32, f32, sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_float, C.c_size_t
 f32p, u64p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
@@ -101,6 +105,7 @@ SIGNATURES = {
     "fvdb_graph_search_dev": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp]),
     "fvdb_graph_search_dev_slot": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp, vp, vp]),
     "fvdb_ctx_device": (i32, [vp]),
+    "fvdb_ctx_info": (i32, [vp, vp]),
     "fvdb_ivf_search_dev_slot": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp, vp, vp]),
     "fvdb_ivf_coarse_dev_slot": (i32, [vp, vp, u32, vp, u32, u32, vp]),
     "fvdb_ivf_search_probes_dev_slot": (i32, [vp, vp, u32, vp, vp, u32, u32, u32, vp, vp, vp, vp]),
@@ -124,7 +129,6 @@ SIGNATURES = {
     "fvdb_comm_unique_id": (i32, [vp]),
     "fvdb_comm_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
     "fvdb_comm_create_hosted": (i32, [vp, i32, i32, vp, vp, C.POINTER(vp)]),
-    "fvdb_comm_create_loopback": (i32, [vp, i32, i32, C.POINTER(vp)]),
     "fvdb_comm_destroy": (None, [vp]),
     "fvdb_comm_rank": (i32, [vp]),
     "fvdb_comm_world": (i32, [vp]),

@@ -79,7 +79,11 @@ struct fvdb_comm {
   ncclComm_t nccl = nullptr;        // RCCL transport
   fvdb_exchange_fn fn = nullptr;    // hosted transport (tests / rehearsal): the caller moves host buffers
   void* user = nullptr;
-  bool loopback = false;            // capacity planning: exchanges are device copies of this rank's own blocks
+#ifdef FVDB_DEV_TOOLS
+  bool loopback = false;            // capacity planning (dev builds only): exchanges are device copies of this rank's own blocks
+#else
+  static constexpr bool loopback = false;
+#endif
   std::mutex mu;                    // one collective at a time per communicator, same order on every rank
   hipEvent_t last = nullptr;        // end of the previous collective of this communicator, on whichever stream it ran
   bool have_last = false;
@@ -125,6 +129,7 @@ int comm_exchange(fvdb_comm* c, fvdb_ctx* on, int op, const Xfer* x, int n) {
     c->have_last = true;
     return FVDB_OK;
   }
+#ifdef FVDB_DEV_TOOLS
   if (c->loopback) {
     for (int i = 0; i < n; ++i)
       for (size_t p = 0; p < W; ++p) {
@@ -133,6 +138,7 @@ int comm_exchange(fvdb_comm* c, fvdb_ctx* on, int op, const Xfer* x, int n) {
       }
     return FVDB_OK;
   }
+#endif
   for (int i = 0; i < n; ++i) {
     const size_t sb = op == XCHG_ALL_GATHER ? x[i].bytes : W * x[i].bytes, rb = W * x[i].bytes;
     HIPCHK(on, c->h_send.ensure(sb));
@@ -211,6 +217,8 @@ int fvdb_comm_create_hosted(fvdb_ctx* ctx, int world, int rank, fvdb_exchange_fn
   return FVDB_OK;
 }
 
+#ifdef FVDB_DEV_TOOLS
+// Development builds only (make dev -> lib_dev/, include/fvdb_dev.h): not part of the product library.
 int fvdb_comm_create_loopback(fvdb_ctx* ctx, int world, int rank, fvdb_comm** out) {
   if (!ctx || !out) return FVDB_E_INVALID;
   *out = nullptr;
@@ -224,6 +232,7 @@ int fvdb_comm_create_loopback(fvdb_ctx* ctx, int world, int rank, fvdb_comm** ou
   *out = c;
   return FVDB_OK;
 }
+#endif
 
 void fvdb_comm_destroy(fvdb_comm* c) {
   if (!c) return;

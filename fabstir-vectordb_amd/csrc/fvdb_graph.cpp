@@ -39,7 +39,7 @@ struct fvdb_graph {
   fvdb_graph_insert_stats last{};
   DBuf s_q, d_counters;
   static constexpr uint32_t kSlots = 16;  // batches that may be in flight at once, each on its own stream
-  DBuf s_visited[kSlots], s_touched[kSlots];
+  DBuf s_visited[kSlots], s_touched[kSlots], s_spill[kSlots];
   uint32_t vis_B[kSlots] = {}, vis_words = 0, vis_tcap = 0, vis_stride = 0;
   bool uploaded = false;
   std::vector<uint8_t> h_deleted;  // host copy of the flags: searches skip the per-neighbour flag load when none is set
@@ -242,6 +242,7 @@ void fvdb_graph_destroy(fvdb_graph* g) {
                   &g->d_stampU, &g->d_state, &g->d_spec, &g->d_elog, &g->s_patch, &g->s_codes, &g->s_q, &g->d_counters};
   for (auto& b : g->s_visited) b.release();
   for (auto& b : g->s_touched) b.release();
+  for (auto& b : g->s_spill) b.release();
   for (DBuf* b : bufs) b->release();
   g->h_state.release();
   g->h_patch.release();
@@ -681,6 +682,10 @@ int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const
     HIPCHK(ctx, g->s_touched[slot].ensure((size_t)B * tcap * 4));
     g->vis_B[slot] = B;
   }
+  // where the restated candidates heap continues when it outgrows its LDS slots (duplicate-heavy data): no node is
+  // admitted twice, so a query never needs more than n slots
+  const uint32_t spill_cap = std::min<uint32_t>(((g->n + 63) / 64) * 64, 8192);
+  HIPCHK(ctx, g->s_spill[slot].ensure((size_t)B * spill_cap * 8));
   // candidate-heap slots of the exact-heap search: it holds every admitted node not yet expanded; a query that
   // overflows it goes to the host walk (data with many duplicate vectors fills it quickly, so it stays generous:
   // at the default tile size the sorted-register kernel's LDS need is larger anyway)
@@ -799,7 +804,7 @@ int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const
     hipLaunchKernelGGL((hnsw_search_fast_kernel<NB_, R_, BY_>), dim3(cdiv(B, 4)), dim3(256), 4 * wave_lds, ctx->stream,   \
                        gv, qd, B, k, ef, cand_cap, wave_lds, g->s_visited[slot].as<uint8_t>(), vstride, words,            \
                        g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev, out_counts_dev,              \
-                       out_status_dev);                                                                                   \
+                       out_status_dev, (HItem*)g->s_spill[slot].p, spill_cap);                                            \
   } while (0)
 #define FVDB_FAST_LAUNCH(NB_, R_)                  \
   do {                                             \
@@ -825,11 +830,11 @@ int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const
   } else if (rh) {
     hipLaunchKernelGGL(hnsw_search_kernel<true>, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
                        g->s_visited[slot].as<uint32_t>(), vstride / 4, g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
-                       out_counts_dev, out_status_dev);
+                       out_counts_dev, out_status_dev, (HItem*)g->s_spill[slot].p, spill_cap);
   } else {
     hipLaunchKernelGGL(hnsw_search_kernel<false>, dim3(B), dim3(64), lds, ctx->stream, gv, qd, B, k, ef, cand_cap,
                        g->s_visited[slot].as<uint32_t>(), vstride / 4, g->s_touched[slot].as<uint32_t>(), tcap, out_nodes_dev, out_dist_dev,
-                       out_counts_dev, out_status_dev);
+                       out_counts_dev, out_status_dev, (HItem*)nullptr, 0u);
   }
   if (ev) {
     (void)hipEventRecord(ev[1], ctx->stream);

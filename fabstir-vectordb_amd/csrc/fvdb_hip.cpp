@@ -4,6 +4,8 @@
 // vectors happens in the kernels; there is no CPU fallback anywhere in this library.
 #include "fvdb_internal.h"
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -972,8 +974,12 @@ int ivf_thr_combine(fvdb_ivf* ivf, const Env& E, const float* u_all, uint32_t W,
   }
   hipLaunchKernelGGL(thr_combine_kernel, dim3(cdiv(B, 256)), dim3(256), 0, ctx->stream, u_all, W, B, S.s_qn2.as<float>(),
                      ivf->d_xmax.as<uint32_t>(), (float)ivf->dpad, ivf->f16 ? 0 : (ivf->pool.half ? 1 : 2), thr_out);
+#ifdef FVDB_DEV_TOOLS
   if (loopback_fill)
     hipLaunchKernelGGL(thr_loopback_fill_kernel, dim3(1), dim3(1024), 0, ctx->stream, thr_out, S.s_qn2.as<float>(), B);
+#else
+  (void)loopback_fill;
+#endif
   HIPCHK(ctx, hipGetLastError());
   return FVDB_OK;
 }
@@ -985,6 +991,22 @@ int check_finite(fvdb_ctx* ctx, const float* x, uint64_t n) {
 }
 
 }  // namespace
+
+// GPU_MAX_HW_QUEUES bookkeeping (fvdb_ctx_create / fvdb_ctx_info): 0 unknown, 1 set by the host application, 2 set by this
+// library before HIP came up, 3 could not be applied (the HIP runtime was already initialised in this process)
+static std::mutex g_hwq_mu;
+static int g_hwq_state = 0, g_hwq_value = 0;
+static bool hip_runtime_already_up() {  // the ROCm runtime holds /dev/kfd open once it is initialised
+  char path[64], tgt[256];
+  for (int fd = 0; fd < 1024; ++fd) {
+    snprintf(path, sizeof path, "/proc/self/fd/%d", fd);
+    const ssize_t n = readlink(path, tgt, sizeof tgt - 1);
+    if (n <= 0) continue;
+    tgt[n] = 0;
+    if (strstr(tgt, "/dev/kfd")) return true;
+  }
+  return false;
+}
 
 // =============================================================================================
 // context
@@ -1000,7 +1022,27 @@ int fvdb_ctx_create(int device, fvdb_ctx** out) {
   // GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue run one after the other.
   // Ask for 16 unless the host application chose a value; this only takes effect if HIP has not been initialised
   // yet in this process (measured: 8 batches in flight, traversal only, 0.42 -> 0.27 ms per 1024-query step).
-  (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
+  // Whether that request can still take effect is recorded for fvdb_ctx_info (and said once on stderr when it cannot).
+  {
+    std::lock_guard<std::mutex> lk(g_hwq_mu);
+    if (g_hwq_state == 0) {
+      const char* set = getenv("GPU_MAX_HW_QUEUES");
+      if (set) {
+        g_hwq_value = atoi(set);
+        g_hwq_state = 1;  // the host application's choice
+      } else if (hip_runtime_already_up()) {
+        g_hwq_value = 4;  // the runtime's default: several batches in flight share hardware queues
+        g_hwq_state = 3;
+        fprintf(stderr, "[fvdb] warning: HIP was initialised before fvdb_ctx_create, so GPU_MAX_HW_QUEUES=16 cannot be applied; "
+                        "with the default of 4 hardware queues batches in flight overlap less (export GPU_MAX_HW_QUEUES=16 before "
+                        "the process touches the GPU)\n");
+      } else {
+        (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
+        g_hwq_value = 16;
+        g_hwq_state = 2;
+      }
+    }
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return FVDB_E_HIP;
   fvdb_ctx* ctx = new (std::nothrow) fvdb_ctx();
@@ -1019,6 +1061,16 @@ int fvdb_ctx_create(int device, fvdb_ctx** out) {
 }
 
 int fvdb_ctx_device(fvdb_ctx* ctx) { return ctx ? ctx->device : -1; }
+
+int fvdb_ctx_info(fvdb_ctx* ctx, fvdb_ctx_info_t* out) {
+  if (!ctx || !out) return FVDB_E_INVALID;
+  std::lock_guard<std::mutex> lk(g_hwq_mu);
+  out->device = ctx->device;
+  out->compute_units = ctx->num_cus;
+  out->hw_queues = g_hwq_value;
+  out->hw_queues_source = g_hwq_state;
+  return FVDB_OK;
+}
 
 void fvdb_ctx_destroy(fvdb_ctx* ctx) {
   if (!ctx) return;

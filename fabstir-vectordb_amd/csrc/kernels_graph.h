@@ -171,31 +171,47 @@ __device__ __forceinline__ void rh_pop(uint32_t& hn, float& hd, uint32_t& n, int
 
 // Heaps too large for registers (`candidates`) stay in LDS, but all lanes help.  Sift-up: the ancestors of the
 // slot are read together, the smaller ones drop one level, the item lands above them.
-__device__ __forceinline__ void lds_sift_up_parallel(HItem* h, uint32_t pos, const HItem c, int lane) {
+//
+// HeapRef: the heap array.  Slots below `cap` live in LDS; a heap that outgrows them continues in a per-query spill
+// area in HBM (data with many equal distances — duplicate vectors — admits thousands of candidates that are never
+// expanded; they used to send the query to the host walk).  The upper levels, where every sift passes, stay on chip.
+struct HeapRef {
+  HItem* lds;
+  HItem* spill;   // may be null when cap is never exceeded
+  uint32_t cap;   // slots in LDS
+  __device__ __forceinline__ HItem get(uint32_t i) const { return i < cap ? lds[i] : spill[i - cap]; }
+  __device__ __forceinline__ void set(uint32_t i, const HItem v) const {
+    if (i < cap) lds[i] = v;
+    else spill[i - cap] = v;
+  }
+};
+
+__device__ __forceinline__ void heap_sift_up_parallel(const HeapRef h, uint32_t pos, const HItem c, int lane) {
   const uint32_t x = pos + 1;  // 1-based index of the slot
   const int depth = 31 - __builtin_clz(x);
   const bool valid = lane >= 1 && lane <= depth;  // lane j holds ancestor j (1 = parent)
   HItem a = c;
-  if (valid) a = h[(x >> lane) - 1];
+  if (valid) a = h.get((x >> lane) - 1);
   const bool moves = valid && !h_le(c, a);
   const uint64_t mb = __ballot(moves) >> 1;                        // bit j-1: ancestor j moves
   const uint32_t m = (uint32_t)__builtin_ctzll(~mb);               // they form a run from the parent up
-  if (valid && (uint32_t)lane <= m) h[(x >> (lane - 1)) - 1] = a;  // ancestor j -> slot of ancestor j-1
-  if (lane == 0) h[(x >> m) - 1] = c;
+  if (valid && (uint32_t)lane <= m) h.set((x >> (lane - 1)) - 1, a);  // ancestor j -> slot of ancestor j-1
+  if (lane == 0) h.set((x >> m) - 1, c);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ void lds_push_parallel(HItem* h, uint32_t& n, const HItem c, int lane) {
-  lds_sift_up_parallel(h, n, c, lane);
+__device__ __forceinline__ void heap_push_parallel(const HeapRef h, uint32_t& n, const HItem c, int lane) {
+  heap_sift_up_parallel(h, n, c, lane);
   n += 1;
 }
 
-// BinaryHeap::pop on an LDS heap: sift_down_to_bottom walks two levels per LDS round trip (children and
-// grandchildren of the hole are fetched together), then the parallel sift-up.  Returns the old root in every lane.
-__device__ __forceinline__ HItem lds_pop_parallel(HItem* h, uint32_t& n, int lane) {
+// BinaryHeap::pop: sift_down_to_bottom walks two levels per round trip (children and grandchildren of the hole are
+// fetched together), then the parallel sift-up.  Returns the old root in every lane.
+__device__ __forceinline__ HItem heap_pop_parallel(const HeapRef h, uint32_t& n, int lane) {
   n -= 1;
-  const HItem item = h[n];
+  const HItem item = h.get(n);
   if (n == 0) return item;
-  const HItem root = h[0];
+  const HItem root = h.get(0);
   const uint32_t end = n;
   uint32_t pos = 0;
   for (;;) {
@@ -203,19 +219,19 @@ __device__ __forceinline__ HItem lds_pop_parallel(HItem* h, uint32_t& n, int lan
     if (c1 >= end) break;  // the hole is a leaf
     const uint32_t idx = lane < 2 ? c1 + lane : 4 * pos + 3 + (lane - 2);  // lanes 2,3 / 4,5: children of c1 / c1+1
     HItem v = item;
-    if (lane < 6 && idx < end) v = h[idx];
+    if (lane < 6 && idx < end) v = h.get(idx);
     const bool two1 = c1 + 1 < end;
     const uint32_t l1 = two1 && rlane_f(v.d, 0) >= rlane_f(v.d, 1) ? 1u : 0u;  // h_le(left, right): right child
     const uint32_t b1 = c1 + l1;
     const HItem cv = HItem{(uint32_t)__builtin_amdgcn_readlane(v.node, l1), rlane_f(v.d, l1)};
     if (!two1) {  // a lone left child at the very end: it moves up and the walk ends
-      if (lane == 0) h[pos] = cv;
+      if (lane == 0) h.set(pos, cv);
       pos = b1;
       break;
     }
     const uint32_t g1 = 2 * b1 + 1, la = 2 + 2 * l1;
     if (g1 >= end) {
-      if (lane == 0) h[pos] = cv;
+      if (lane == 0) h.set(pos, cv);
       pos = b1;
       break;
     }
@@ -223,15 +239,24 @@ __device__ __forceinline__ HItem lds_pop_parallel(HItem* h, uint32_t& n, int lan
     const uint32_t l2 = two2 && rlane_f(v.d, la) >= rlane_f(v.d, la + 1) ? la + 1 : la;
     const HItem gv = HItem{(uint32_t)__builtin_amdgcn_readlane(v.node, l2), rlane_f(v.d, l2)};
     if (lane == 0) {
-      h[pos] = cv;
-      h[b1] = gv;
+      h.set(pos, cv);
+      h.set(b1, gv);
     }
     pos = g1 + (l2 - la);
     if (!two2) break;
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  lds_sift_up_parallel(h, pos, item, lane);
+  heap_sift_up_parallel(h, pos, item, lane);
   return root;
+}
+
+// the same on a heap that lives in LDS whole
+__device__ __forceinline__ void lds_push_parallel(HItem* h, uint32_t& n, const HItem c, int lane) {
+  heap_push_parallel(HeapRef{h, nullptr, 0xFFFFFFFFu}, n, c, lane);
+}
+__device__ __forceinline__ HItem lds_pop_parallel(HItem* h, uint32_t& n, int lane) {
+  return heap_pop_parallel(HeapRef{h, nullptr, 0xFFFFFFFFu}, n, lane);
 }
 
 // Distances of the wave's query to the `np` (<= 64) rows listed in pending[], into pdist[]: one lane per row,
@@ -340,7 +365,8 @@ __device__ __forceinline__ void hnsw_search_exact_body(const GraphView& g, const
                                                        uint32_t words, uint32_t* __restrict__ tch /* its visited log */, uint32_t tcap,
                                                        uint32_t* __restrict__ out_nodes, float* __restrict__ out_dist,
                                                        uint32_t* __restrict__ out_counts, uint32_t* __restrict__ out_status,
-                                                       unsigned char* lds, int lane) {
+                                                       unsigned char* lds, int lane, HItem* __restrict__ spill = nullptr /* this query's */,
+                                                       uint32_t spill_cap = 0) {
   const uint32_t dpad = g.dpad;
   float* q_lds = (float*)lds;
   float* pf_scratch = q_lds + dpad;
@@ -382,7 +408,7 @@ __device__ __forceinline__ void hnsw_search_exact_body(const GraphView& g, const
     // ---- search_layer(query, res[0].node, ef, layer) ----
     const HItem ep = res[0];
     if (RH) {
-      lds_push_parallel(cand, nC, ep, lane);
+      heap_push_parallel(HeapRef{cand, spill, cand_cap}, nC, ep, lane);
       rh_push(nr_node, nr_d, nN, ep.node, -ep.d, lane);
       if (lane == 0) {
         atomicOr(&vis[ep.node >> 5], 1u << (ep.node & 31));
@@ -400,7 +426,7 @@ __device__ __forceinline__ void hnsw_search_exact_body(const GraphView& g, const
       if (RH) {
         uint32_t stop_r = 1, node_r = 0;
         if (nC > 0) {
-          const HItem cur = lds_pop_parallel(cand, nC, lane);
+          const HItem cur = heap_pop_parallel(HeapRef{cand, spill, cand_cap}, nC, lane);
           stop_r = cur.d > -rlane_f(nr_d, 0) ? 1u : 0u;  // :499-501
           node_r = cur.node;
         }
@@ -484,12 +510,12 @@ __device__ __forceinline__ void hnsw_search_exact_body(const GraphView& g, const
             todo &= todo - 1;
             const float d = rlane_f(pd, i);
             if (d < worst || nN < ef) {
-              if (nC >= cand_cap) {
+              if (nC >= cand_cap + spill_cap) {
                 overflow = true;
                 break;
               }
               const uint32_t node_i = __builtin_amdgcn_readlane(pn, i);
-              lds_push_parallel(cand, nC, HItem{node_i, d}, lane);
+              heap_push_parallel(HeapRef{cand, spill, cand_cap}, nC, HItem{node_i, d}, lane);
               rh_push(nr_node, nr_d, nN, node_i, -d, lane);
               if (nN > ef) rh_pop(nr_node, nr_d, nN, lane);
               worst = -rlane_f(nr_d, 0);
@@ -617,12 +643,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 3))) void
                                                          uint32_t words, uint32_t* __restrict__ touched /* [B][tcap] */,
                                                          uint32_t tcap, uint32_t* __restrict__ out_nodes,
                                                          float* __restrict__ out_dist, uint32_t* __restrict__ out_counts,
-                                                         uint32_t* __restrict__ out_status) {
+                                                         uint32_t* __restrict__ out_status, HItem* __restrict__ spill /* [B][spill_cap] */,
+                                                         uint32_t spill_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const uint32_t b = blockIdx.x;
   if (b >= B) return;
   hnsw_search_exact_body<RH>(g, queries, b, k, ef_final, cand_cap, visited + (size_t)b * words, words, touched + (size_t)b * tcap, tcap, out_nodes, out_dist, out_counts,
-                             out_status, lds, (int)threadIdx.x);
+                             out_status, lds, (int)threadIdx.x, spill ? spill + (size_t)b * spill_cap : nullptr, spill ? spill_cap : 0u);
 }
 
 }  // namespace fvdb

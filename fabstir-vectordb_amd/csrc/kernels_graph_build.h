@@ -217,8 +217,12 @@ __device__ __forceinline__ float wave_min_f(float v) {
 // are spelled out: hipcc does not insert them around an asm statement.
 __device__ __forceinline__ uint32_t writelane_u(uint32_t value, uint32_t l, uint32_t old) {
   const uint32_t sv = __builtin_amdgcn_readfirstlane(value), sl = __builtin_amdgcn_readfirstlane(l);
-  // gfx9 allows one SGPR operand per VALU instruction: the lane select travels in M0
-  asm volatile("s_nop 3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0\n\ts_nop 1" : "+v"(old) : "s"(sv), "s"(sl) : "m0");
+  // gfx9 allows one SGPR operand per VALU instruction: the lane select travels in M0, whose value (the compiler's) is
+  // put back afterwards
+  uint32_t keep;
+  asm volatile("s_nop 3\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1\n\ts_nop 1"
+               : "+v"(old), "=&s"(keep)
+               : "s"(sv), "s"(sl));
   return old;
 }
 

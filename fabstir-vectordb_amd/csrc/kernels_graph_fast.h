@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256, (R <= 8 ? 4 : (R <= 12 ? 3 : FVDB_FAST_WAVES16
                                                               uint32_t words, uint32_t* __restrict__ touched /* [B][tcap] */,
                                                               uint32_t tcap, uint32_t* __restrict__ out_nodes,
                                                               float* __restrict__ out_dist, uint32_t* __restrict__ out_counts,
-                                                              uint32_t* __restrict__ out_status) {
+                                                              uint32_t* __restrict__ out_status, HItem* __restrict__ spill /* [B][spill_cap] */,
+                                                              uint32_t spill_cap) {
   // four independent waves per workgroup (one query each; no workgroup-level synchronisation anywhere): a grid of
   // B/4 workgroups of 4 waves spreads over the CUs one wave per SIMD, where B single-wave workgroups were seen to
   // leave a straggler waiting for a slot behind long-running waves
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256, (R <= 8 ? 4 : (R <= 12 ? 3 : FVDB_FAST_WAVES16
     // equal distances met inside the heaps: this query is searched again, from the start, with the reference's heaps
     // restated (kernels_graph.h) — same wave, same launch; the visited bitmap was left clean above
     hnsw_search_exact_body<true>(g, queries, b, k, ef_final, cand_cap, vis, words, tch, tcap, out_nodes, out_dist,
-                                 out_counts, out_status, lds_f, lane);
+                                 out_counts, out_status, lds_f, lane, spill ? spill + (size_t)b * spill_cap : nullptr, spill ? spill_cap : 0u);
     return;
   }
   if (status) {

@@ -712,6 +712,7 @@ __global__ void thr_combine_kernel(const float* __restrict__ u_all, uint32_t W, 
   for (uint32_t w = 0; w < W; ++w) m = fminf(m, u_all[(size_t)w * n + i]);
   thr[i] = m + mfma_error_bound(__uint_as_float(*xmax_bits), qn[i], d, rows_f16);
 }
+#ifdef FVDB_DEV_TOOLS
 // Loopback communicator only (capacity planning, fvdb_comm_create_loopback): the peers that would have supplied the
 // thresholds of the queries whose list this rank does not own do not exist, so those entries get a typical one — the
 // mean of the known (thr + |q|^2), i.e. a typical squared distance of the (k+6)-th neighbour, minus the query's |q|^2.
@@ -742,6 +743,7 @@ __global__ __launch_bounds__(1024) void thr_loopback_fill_kernel(float* __restri
   for (uint32_t i = threadIdx.x; i < n; i += 1024)
     if (!(thr[i] < __builtin_huge_valf())) thr[i] = typ - qn[i];
 }
+#endif
 __global__ void fill_f32_kernel(float* __restrict__ p, uint32_t n, float v) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

@@ -106,6 +106,13 @@ class Context:
         except Exception:
             pass
 
+    def info(self):
+        """device, compute units, and the hardware-queue count batches in flight can use (fvdb_ctx_info): hw_queues_source
+        1 = set by the host, 2 = set by the library, 3 = could not be applied (HIP was initialised first)."""
+        v = (C.c_int * 4)()
+        self.check(self.lib.fvdb_ctx_info(self.h, C.cast(v, C.c_void_p)))
+        return dict(device=v[0], compute_units=v[1], hw_queues=v[2], hw_queues_source=v[3])
+
     def device_synchronize(self):
         """Wait for every stream of this context's device (the engine keeps one stream per batch in flight)."""
         self.check(self.lib.fvdb_device_synchronize(self.h))

@@ -275,6 +275,8 @@ void* fvh_hybrid_hnsw(void* p) { return &((HybridIndex*)p)->recent(); }
 void fvh_hybrid_set_sequential_graph(void* p, int on) { ((HybridIndex*)p)->set_sequential_graph(on != 0); }
 int fvh_hybrid_sequential_graph(void* p) { return ((HybridIndex*)p)->sequential_graph(); }
 double fvh_hybrid_recent_build_seconds(void* p) { return ((HybridIndex*)p)->recent_build_seconds(); }
+void fvh_hybrid_set_blocking_writers(void* p, int on) { ((HybridIndex*)p)->set_blocking_writers(on != 0); }
+int fvh_hybrid_blocking_writers(void* p) { return ((HybridIndex*)p)->blocking_writers(); }
 void* fvh_hybrid_ivf(void* p) { return &((HybridIndex*)p)->historical(); }
 
 }  // extern "C"

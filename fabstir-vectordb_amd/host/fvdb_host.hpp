@@ -390,7 +390,13 @@ class HybridIndex {
   // traversal state, IVF scratch set, result blocks) and returns it.  Mutations wait for those calls to finish.
   // The explicit search_dev_begin/_end pair is for ONE thread keeping several batches in flight; while such a batch
   // is uncollected, mutations are refused (INVALID) rather than waited for.
-  bool busy() const {  // some batch is in flight: inserts / deletes are refused until it is collected
+  // What a mutation (insert, delete, migrate, vacuum) does while batches begun with search_dev_begin are uncollected:
+  // false (default) = returns FVDB_E_INVALID at once; true = waits for them to be collected, like the reference's write
+  // guard waits for its readers (src/hybrid/core.rs:457,466) — for hosts whose searches and writes run on different
+  // threads (a thread that waits for its OWN uncollected batch would wait for ever).
+  void set_blocking_writers(bool on) { writers_wait_ = on; }
+  bool blocking_writers() const { return writers_wait_; }
+  bool busy() const {  // some batch is in flight: inserts / deletes are refused (or wait) until it is collected
     std::lock_guard<std::mutex> lk(slot_mu_);
     for (const Slot& s : slots_)
       if (s.active) return true;
@@ -437,6 +443,9 @@ class HybridIndex {
                  int shard_mode = -1);
   int build_recent(const uint64_t* ids, const float* v, uint64_t n, uint32_t dim);
   bool sequential_graph_ = true;
+  std::atomic<bool> writers_wait_{false};
+  // exclusive access for a mutation: with no batch in flight, or FVDB_E_INVALID / after waiting (set_blocking_writers)
+  int write_lock(std::unique_lock<std::shared_mutex>& w);
   double recent_build_s_ = 0.0;
   fvdb_comm* comm_ = nullptr;
   fvdb_sharded* sharded_ = nullptr;

@@ -52,12 +52,26 @@ int HybridIndex::set_ivf_centroids(const float* c, uint32_t dim) {
   return FVDB_OK;
 }
 
+// The write guard.  Waiting happens WITHOUT holding rw_ (a searcher that is about to collect its batches may need the
+// read side first), and a begin takes the read side while it marks its slot active, so no batch can start under a
+// mutation.
+int HybridIndex::write_lock(std::unique_lock<std::shared_mutex>& w) {
+  for (;;) {
+    w.lock();  // the blocking searches of other threads hold the read side for their whole duration: waited for here
+    if (!busy()) return FVDB_OK;
+    w.unlock();  // what is left in flight was begun with search_dev_begin and not collected yet
+    if (!writers_wait_) return FVDB_E_INVALID;
+    std::unique_lock<std::mutex> lk(slot_mu_);
+    slot_cv_.wait(lk, [&] { return !busy_unlocked(); });
+  }
+}
+
 // src/hybrid/core.rs:357-417
 int HybridIndex::insert_with_timestamp(uint64_t id, const float* v, uint32_t dim, double ts, double now,
                                        int64_t level) {
   if (!initialized_) return FVDB_E_NOT_INITIALIZED;
-  std::unique_lock<std::shared_mutex> w(rw_);  // waits for the blocking searches of other threads (write guard)
-  if (busy()) return FVDB_E_INVALID;  // a search begun with search_dev_begin has not been collected yet
+  std::unique_lock<std::shared_mutex> w(rw_, std::defer_lock);  // waits for the blocking searches of other threads (write guard)
+  if (int rc = write_lock(w)) return rc;
   if (timestamps_.count(id)) return FVDB_E_DUPLICATE;
   bool to_recent = !ivf_trained_ || age_of(now, ts) < cfg_.recent_threshold_s;
   if (to_recent) {
@@ -237,8 +251,8 @@ int HybridIndex::from_parts(const uint64_t* ids, const double* ts, uint64_t n, u
 
 // src/hybrid/core.rs:989-1012
 int HybridIndex::vacuum(uint64_t* hnsw_removed, uint64_t* ivf_removed) {
-  std::unique_lock<std::shared_mutex> w(rw_);
-  if (busy()) return FVDB_E_INVALID;
+  std::unique_lock<std::shared_mutex> w(rw_, std::defer_lock);
+  if (int rc = write_lock(w)) return rc;
   *hnsw_removed = recent_->vacuum();
   return historical_->vacuum(ivf_removed);
 }
@@ -252,8 +266,8 @@ void HybridIndex::export_timestamps(uint64_t* ids, double* ts) const {
 
 // src/hybrid/core.rs:600-649 — copies into IVF, never removes from HNSW (:577-581)
 uint64_t HybridIndex::migrate_with_threshold(double threshold_s, double now) {
-  std::unique_lock<std::shared_mutex> w(rw_);
-  if (busy()) return 0;
+  std::unique_lock<std::shared_mutex> w(rw_, std::defer_lock);
+  if (write_lock(w)) return 0;
   return migrate_locked(threshold_s, now);
 }
 
@@ -367,6 +381,7 @@ int HybridIndex::search_dev_begin(uint32_t slot, const float* q_dev, uint32_t B,
       migrate_locked(cfg_.recent_threshold_s, now);
     }
   }
+  std::shared_lock<std::shared_mutex> r(rw_);  // no mutation is under way while the batch is enqueued
   {
     std::lock_guard<std::mutex> lk(slot_mu_);
     if (sl.active) return FVDB_E_INVALID;
@@ -397,6 +412,7 @@ uint32_t HybridIndex::sharded_rows(uint32_t B, int mode) const {
 int HybridIndex::search_sharded_begin(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim,
                                       const HybridSearchConfig& cfg, int mode) {
   if (slot >= kSlots || !sharded_ || (mode != FVDB_SHARD_WEAK && mode != FVDB_SHARD_STRONG)) return FVDB_E_INVALID;
+  std::shared_lock<std::shared_mutex> r(rw_);
   {
     std::lock_guard<std::mutex> lk(slot_mu_);
     if (slots_[slot].active) return FVDB_E_INVALID;
@@ -665,8 +681,8 @@ int HybridIndex::search_with_filter(const float* q, uint32_t B, uint32_t dim, ui
 
 // delete: src/hybrid/core.rs:904-937
 int HybridIndex::remove(uint64_t id, double now) {
-  std::unique_lock<std::shared_mutex> w(rw_);
-  if (busy()) return FVDB_E_INVALID;  // a search begun with search_dev_begin has not been collected yet
+  std::unique_lock<std::shared_mutex> w(rw_, std::defer_lock);
+  if (int rc = write_lock(w)) return rc;
   auto it = timestamps_.find(id);
   if (it == timestamps_.end()) return FVDB_E_NOT_FOUND;
   if (age_of(now, it->second) < cfg_.recent_threshold_s) return recent_->mark_deleted(id);

@@ -17,7 +17,7 @@ from .engine import (STATUS_TO_EXC, DimensionMismatch, FvdbError, InconsistentDi
                      InsufficientTrainingData, InvalidConfig, _f32, _ptr)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HOST_LIB_PATH = os.path.join(_HERE, "lib", "libfvdb_host.so")
+HOST_LIB_PATH = os.path.join(_capi.LIB_DIR, "libfvdb_host.so")
 _host = None
 i64p = C.POINTER(C.c_int64)
 f64p = C.POINTER(C.c_double)
@@ -108,6 +108,8 @@ HOST_SIGNATURES = {
     "fvh_hybrid_set_sequential_graph": (None, [vp, i32]),
     "fvh_hybrid_sequential_graph": (i32, [vp]),
     "fvh_hybrid_recent_build_seconds": (dbl, [vp]),
+    "fvh_hybrid_set_blocking_writers": (None, [vp, i32]),
+    "fvh_hybrid_blocking_writers": (i32, [vp]),
     "fvh_hybrid_ivf": (vp, [vp]),
 }
 
@@ -528,6 +530,11 @@ class HybridIndex(_Base):
 
     def sequential_graph(self):
         return bool(self.lib.fvh_hybrid_sequential_graph(self.h))
+
+    def set_blocking_writers(self, on):
+        """Mutations while batches begun with search_dev_begin are uncollected: False (default) = FvdbError(INVALID) at once,
+        True = wait until they are collected (the reference's write guard; for searches and writes on different threads)."""
+        self.lib.fvh_hybrid_set_blocking_writers(self.h, int(bool(on)))
 
     def recent_build_seconds(self):
         return float(self.lib.fvh_hybrid_recent_build_seconds(self.h))

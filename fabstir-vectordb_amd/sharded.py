@@ -128,9 +128,14 @@ class Comm:
 
     @classmethod
     def loopback(cls, ctx, world, rank=0):
-        """Capacity planning on one GPU (fvdb_comm_create_loopback): rank `rank` of a pretended `world`-rank job."""
+        """Capacity planning on one GPU: rank `rank` of a pretended `world`-rank job.  Development builds only
+        (include/fvdb_dev.h; `make -C fabstir-vectordb_amd dev`, FVDB_LIB_DIR=lib_dev) — the product library has no such entry point."""
+        fn = getattr(ctx.lib, "fvdb_comm_create_loopback", None)
+        if fn is None:
+            raise RuntimeError("the loopback communicator exists in the dev build only: make -C fabstir-vectordb_amd dev, FVDB_LIB_DIR=lib_dev")
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         h = C.c_void_p()
-        ctx.check(ctx.lib.fvdb_comm_create_loopback(ctx.h, world, rank, C.byref(h)))
+        ctx.check(fn(ctx.h, world, rank, C.byref(h)))
         return cls(ctx, h, world, rank)
 
     def all_gather_dev(self, send_dev, recv_dev, nbytes, on=None):

@@ -76,6 +76,15 @@ void fvdb_ctx_destroy(fvdb_ctx* ctx);
 int fvdb_ctx_synchronize(fvdb_ctx* ctx);
 int fvdb_device_synchronize(fvdb_ctx* ctx); /* every stream of ctx's device (hipDeviceSynchronize) */
 int fvdb_ctx_device(fvdb_ctx* ctx); /* the device ordinal the context was created on */
+/* Batches in flight run on streams of their own; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues
+ * (default 4), and kernels of streams sharing a queue run one after the other.  fvdb_ctx_create asks for 16 unless the host
+ * application set the variable itself — which only works if HIP has not been initialised in the process yet.
+ * hw_queues_source: 1 = the host application's setting, 2 = set by this library, 3 = could NOT be applied (HIP was already
+ * up; hw_queues then reports the runtime's default and a warning went to stderr: expect ~35 % less overlap). */
+typedef struct fvdb_ctx_info_t {
+  int device, compute_units, hw_queues, hw_queues_source;
+} fvdb_ctx_info_t;
+int fvdb_ctx_info(fvdb_ctx* ctx, fvdb_ctx_info_t* out);
 void* fvdb_ctx_stream(fvdb_ctx* ctx);          /* hipStream_t, for callers that interleave work */
 const char* fvdb_last_error(fvdb_ctx* ctx);    /* message of the last failing call on ctx */
 const char* fvdb_version(void);
@@ -401,11 +410,6 @@ typedef int (*fvdb_exchange_fn)(void* user, int op, const void* send_host, void*
 int fvdb_comm_unique_id(void* out128);
 int fvdb_comm_create(fvdb_ctx* ctx, const void* id128, int world, int rank, fvdb_comm** out);
 int fvdb_comm_create_hosted(fvdb_ctx* ctx, int world, int rank, fvdb_exchange_fn fn, void* user, fvdb_comm** out);
-/* Capacity planning on ONE GPU: a communicator of `world` ranks whose exchanges are device-to-device copies of this
- * rank's own blocks (every peer is pretended to have sent what this rank sent).  Results are meaningless; the step's
- * kernels, buffer sizes and stream ordering are exactly those of rank `rank` in a real `world`-rank job, so its time is
- * the per-rank step time less the fabric.  bench.py --emulate-world N. */
-int fvdb_comm_create_loopback(fvdb_ctx* ctx, int world, int rank, fvdb_comm** out);
 void fvdb_comm_destroy(fvdb_comm* comm);
 int fvdb_comm_rank(fvdb_comm* comm);
 int fvdb_comm_world(fvdb_comm* comm);

@@ -86,3 +86,16 @@ def test_bench_refuses_a_multi_gpu_line_without_rccl():
     p = _bench(["--gpus", "2"], timeout=600)
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")], p.stdout[:2000]
+
+
+def test_dev_build_loopback_communicator_runs_a_rank_of_a_larger_job():
+    # the capacity-planning communicator is compiled into the dev build only (make dev -> lib_dev/, -DFVDB_DEV_TOOLS):
+    # a child process loads that build through FVDB_LIB_DIR and runs rank 1 of a pretended 4-rank job
+    if _gpu_initialised_here():
+        pytest.skip("this process already holds the GPU; run this module first (it sorts first by name)")
+    root = os.path.dirname(HERE)
+    if not os.path.exists(os.path.join(root, "fabstir-vectordb_amd", "lib_dev", "libfvdb_hip.so")):
+        pytest.skip("dev build absent (make -C fabstir-vectordb_amd dev)")
+    env = dict(os.environ, FVDB_LIB_DIR="lib_dev")
+    p = subprocess.run([sys.executable, os.path.join(HERE, "_loopback_child.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "loopback child ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]

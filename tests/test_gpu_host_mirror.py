@@ -506,6 +506,45 @@ def test_hybrid_refuses_mutation_while_a_batch_is_in_flight(fv, ctx):
     assert g.migrate_with_threshold(0.5 * DAY, now) > 0
 
 
+def test_blocking_writers_wait_for_the_batches_in_flight(fv, ctx):
+    # set_blocking_writers: an insert issued (on another thread) while a batch is uncollected waits for the collector,
+    # like the reference's write guard waits for its readers (src/hybrid/core.rs:457,466), and then goes through
+    import threading
+    import time
+    n, d, nlist = 400, 16, 4
+    x = mixture(n, d, n_comp=4, seed=97)
+    now = 1000 * DAY
+    g = fv.HybridIndex(ctx, max_connections=8, max_connections_layer_0=16, ef_construction=40, n_clusters=nlist, n_probe=4)
+    g.set_ivf_centroids(x[:nlist].copy())
+    for i in range(n):
+        g.insert_with_timestamp(i, x[i], now - (1 if i % 3 else 30) * DAY, now)
+    g.set_blocking_writers(True)
+    q = g.ctx.upload(mixture(16, d, n_comp=4, seed=98))
+    want = g.search_dev(q, 16, 5, now=now, hnsw_ef=30, ivf_n_probe=4, dim=d)
+    g.search_dev_begin(0, q, 16, 5, now=now, hnsw_ef=30, ivf_n_probe=4, dim=d)
+    done = {}
+
+    def writer():
+        g.insert_with_timestamp(n, x[0] + 1, now, now)
+        done["t"] = time.time()
+
+    th = threading.Thread(target=writer)
+    th.start()
+    time.sleep(0.3)
+    assert th.is_alive() and "t" not in done      # waiting, not refused
+    t_end = time.time()
+    got = g.search_dev_end(0)                       # the batch is collected: the writer may go
+    th.join(10)
+    assert not th.is_alive() and done["t"] >= t_end
+    assert np.array_equal(got.ids, want.ids)        # the batch saw the index as it was
+    assert g.recent_count() + g.historical_count() == n + 1
+    g.set_blocking_writers(False)
+    g.search_dev_begin(0, q, 16, 5, now=now, hnsw_ef=30, ivf_n_probe=4, dim=d)
+    with pytest.raises(fv.FvdbError):               # the default: refused at once
+        g.delete(5, now)
+    g.search_dev_end(0)
+
+
 def test_hybrid_vacuum_matches_oracle(fv, ctx):
     # src/hybrid/core.rs:989-1012 -> src/hnsw/operations.rs:176-200 + src/ivf/operations.rs:625-645: soft-deleted
     # vectors leave the graph (and every neighbour set) and their lists; searches, later inserts and the graph itself

@@ -228,3 +228,15 @@ def test_search_with_filter_in_the_host_mirror(fv, ctx):
     assert np.all(g.search_with_filter(q, k, lambda rid: False, now=now).counts == 0)
     with pytest.raises(ZeroDivisionError):  # an exception inside the predicate surfaces after the call returns
         g.search_with_filter(q[:1], k, lambda rid: 1 // 0, now=now)
+
+
+def test_ctx_info_reports_the_hardware_queue_setting(fv, ctx):
+    # fvdb_ctx_create asks for 16 hardware queues (several batches in flight) unless the host chose a value; the context
+    # says which case applies, so a host that initialised HIP first can see that the request came too late
+    info = ctx.info()
+    assert info["device"] == 0 and info["compute_units"] >= 64
+    assert info["hw_queues_source"] in (1, 2, 3)
+    if info["hw_queues_source"] == 2:
+        assert info["hw_queues"] == 16
+    if info["hw_queues_source"] == 3:
+        assert info["hw_queues"] == 4

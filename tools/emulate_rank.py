@@ -6,10 +6,13 @@ threshold exchange are device copies of its own blocks, so buffer sizes, kernels
 and only the fabric is missing.  Results are NOT search results.  Prints ms per step with 8 steps in flight for
 W = 1 (the plain single-GPU step), then weak and strong mode at each W given.
 
-usage: python tools/emulate_rank.py [W ...]   (default 2 4 8)"""
+Needs the DEVELOPMENT build of the engine (the loopback communicator is not in the product library):
+    make -C fabstir-vectordb_amd dev && FVDB_LIB_DIR=lib_dev python tools/emulate_rank.py [W ...]   (default 2 4 8)"""
 import os
 import sys
 import time
+
+os.environ.setdefault("FVDB_LIB_DIR", "lib_dev")
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
