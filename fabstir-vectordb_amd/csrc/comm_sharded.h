@@ -325,11 +325,32 @@ int fvdb_ivf_search_sharded_begin(fvdb_sharded* s, fvdb_ctx* on, uint32_t slot, 
     HIPCHK(ctx, hipMemsetAsync(sl.keys.as<uint64_t>() + (size_t)Bq * k, 0xFF, (size_t)(Bs - Bq) * k * 8, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(sl.ids.as<uint64_t>() + (size_t)Bq * k, 0xFF, (size_t)(Bs - Bq) * k * 8, ctx->stream));
   }
-  // 1. centroid ranking for the queries this rank was handed
-  int rc = fvdb_ivf_coarse_dev_slot(ivf, on, slot, q_dev, B, nprobe, sl.probes.as<uint32_t>());
-  if (rc) return rc;
+  // 1. centroid ranking.  WEAK: the rank's own B queries.  STRONG: the batch is the same on every rank, so each rank
+  //    ranks the centroids for ITS slice of it only (the slice whose results it will produce) and the probe lists are
+  //    all-gathered (Bo * nprobe * 4 B per rank) — 1/W of the ranking work per rank instead of all of it on every rank
+  //    (FVDB_STRONG_SPLIT=0: every rank ranks every query, no exchange; for A/B runs)
+  static const bool strong_split = !(getenv("FVDB_STRONG_SPLIT") && atoi(getenv("FVDB_STRONG_SPLIT")) == 0);
+  int rc = FVDB_OK;
   const float* q_scan = q_dev;
   const uint32_t* probes_scan = sl.probes.as<uint32_t>();
+  if (!weak && W > 1 && strong_split) {
+    const uint32_t lo = std::min(B, (uint32_t)c->rank * Bo), mine = std::min(Bo, B - lo);
+    HIPCHK(ctx, sl.probes.ensure((size_t)Bo * np * 4));
+    HIPCHK(ctx, sl.probes_all.ensure((size_t)W * Bo * np * 4));
+    if (mine < Bo)  // the last slices may be short or empty: "no list" entries, skipped by the plan kernels
+      HIPCHK(ctx, hipMemsetAsync(sl.probes.as<uint32_t>() + (size_t)mine * np, 0xFF, (size_t)(Bo - mine) * np * 4, ctx->stream));
+    if (mine) {
+      rc = fvdb_ivf_coarse_dev_slot(ivf, on, slot, q_dev + (size_t)lo * d, mine, nprobe, sl.probes.as<uint32_t>());
+      if (rc) return rc;
+    }
+    const Xfer x[1] = {{sl.probes.p, sl.probes_all.p, (size_t)Bo * np * 4}};
+    rc = comm_exchange(c, ctx, XCHG_ALL_GATHER, x, 1);
+    if (rc) return rc;
+    probes_scan = sl.probes_all.as<uint32_t>();  // row q = slice * Bo + i: the global query index
+  } else {
+    rc = fvdb_ivf_coarse_dev_slot(ivf, on, slot, q_dev, B, nprobe, sl.probes.as<uint32_t>());
+    if (rc) return rc;
+  }
   if (weak && W > 1) {  // exchange 1: every rank needs every query, with the probe list it came with
     HIPCHK(ctx, sl.q_all.ensure((size_t)Bq * d * 4));
     HIPCHK(ctx, sl.probes_all.ensure((size_t)Bq * np * 4));

@@ -181,7 +181,7 @@ struct fvdb_ivf : IvfScratch {
   uint32_t backoff_len = 0;
   // the second filter pass for queries whose survivors outgrew the buffer (refine_threshold_kernel) costs five small
   // launches per batch: AUTO enqueues them only while such queries have been seen recently (counters [2] and [6])
-  uint64_t overflow_seen = 0;
+  uint64_t overflow_seen = 0, overflow_q = 0;
   uint32_t refine_batches_left = 0;
   DBuf d_xmax;           // max |x|^2 over the rows ever added (float bits)
   Pool cpool;
@@ -697,13 +697,14 @@ int run_fine_mfma(fvdb_ivf* ivf, const Env& E, const float* qpad, uint32_t B, ui
   bool refine = !E.given_thr && !no_refine;
   if (refine && ivf->scan_mode == FVDB_SCAN_AUTO) {
     std::lock_guard<std::mutex> lk(ivf->mu);
-    if (ivf->h_fb.p) {
+    if (ivf->h_fb.p && ivf->mfma_q - ivf->overflow_q >= 2048) {
+      // worth five more launches per batch once more than one query in a thousand overflows (a stray one is cheaper to
+      // rescan exactly); looked at every 2048 queries, the counters lag by the batches in flight
       const volatile uint32_t* c = (const volatile uint32_t*)ivf->h_fb.p;
-      const uint64_t now = (uint64_t)c[2] + c[6];
-      if (now != ivf->overflow_seen) {
-        ivf->overflow_seen = now;
-        ivf->refine_batches_left = 1024;
-      }
+      const uint64_t now = (uint64_t)c[2] + c[6], dq = ivf->mfma_q - ivf->overflow_q;
+      if ((now - ivf->overflow_seen) * 1000 > dq) ivf->refine_batches_left = 1024;
+      ivf->overflow_seen = now;
+      ivf->overflow_q = ivf->mfma_q;
     }
     if (ivf->refine_batches_left > 0) ivf->refine_batches_left -= 1;
     else refine = false;
@@ -1315,7 +1316,7 @@ static int install_centroids(fvdb_ivf* ivf, const float* d_rowmajor /* device [n
   if (ivf->h_fb.p) *(volatile uint32_t*)ivf->h_fb.p = 0;
   ivf->mfma_q = ivf->fb_seen = ivf->q_seen = 0;
   ivf->exact_batches_left = ivf->backoff_len = 0;
-  ivf->overflow_seen = 0;
+  ivf->overflow_seen = ivf->overflow_q = 0;
   ivf->refine_batches_left = 0;
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -254,9 +254,10 @@ def test_isotropic_survey_generator_has_no_cliff(fv, ctx):
     cpu.batch_insert(ids, x)
     oi, od, oc = cpu.batch_search(q[:48], k, nprobe, threads=4)
     assert np.array_equal(got.ids[:48], oi) and np.array_equal(bits(got.distances[:48]), bits(od))
-    # AUTO learns it from the counters: after the first batches with overflowing queries the second pass is enqueued
+    # AUTO learns it from the counters (looked at every 2048 queries): once more than one query in a thousand overflows,
+    # the second pass is enqueued
     ctx.check(lib.fvdb_ivf_set_scan_mode(h, 0))
-    for _ in range(6):
+    for _ in range(30):
         auto = ivf.search(q, k, nprobe)
         assert np.array_equal(auto.ids, exact.ids) and np.array_equal(bits(auto.distances), bits(exact.distances))
     f2, r2 = counters()
