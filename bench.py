@@ -565,12 +565,12 @@ def build_roofline(args, d, B, rows_out, world, stage, n_prof, stats, graph_ms_s
     # HBM-side traffic from PMC counters (FETCH_SIZE / WRITE_SIZE in their own rocprofv3 passes, tools/pmc_traffic.sh;
     # gfx950: FETCH_SIZE counts wide streaming reads at half their bytes => doubled, see MI355X_MICROARCH.md)
     try:
-        pmj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        pmj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
         if args.n == pmj.get("n_vectors") and world == 1:
             g = pmj.get("graph_traversal")
             if g:
                 roofline["traffic"] = int((2 * g["FETCH_SIZE_KB_avg"] + g["WRITE_SIZE_KB_avg"]) * 1024)
-                roofline["traffic_note"] = "bytes per launch beyond L2 (Infinity Cache + HBM), 2*FETCH_SIZE+WRITE_SIZE, profiles/r02_pmc_traffic.json"
+                roofline["traffic_note"] = "bytes per launch beyond L2 (Infinity Cache + HBM), 2*FETCH_SIZE+WRITE_SIZE, profiles/r03_pmc_traffic.json"
             ls = pmj.get("list_scan")
             if ls and mfma_path:
                 roofline["list_scan"]["traffic"] = int((2 * ls["FETCH_SIZE_KB_avg"] + ls["WRITE_SIZE_KB_avg"]) * 1024)

@@ -3,7 +3,7 @@
 #   FETCH_SIZE / WRITE_SIZE   bytes beyond L2 (gfx950: FETCH_SIZE counts wide streaming reads at half their bytes)
 #   SQ_VALU_MFMA_BUSY_CYCLES  matrix-core busy cycles, against SQ_BUSY_CU_CYCLES / GRBM_GUI_ACTIVE
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ARGS="--steps 20 --warmup 2 --no-cpu-baseline --compare-host-walk 0 --nprobe 32 --ef 50 --query-batches 8"
+ARGS="--steps 20 --warmup 2 --no-cpu-baseline --compare-host-walk 0 --insert-sample 0 --nprobe 32 --ef 50 --query-batches 8"
 rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma gpurun_out/pmc_busy
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py $ARGS > gpurun_out/pmc_bench.json 2> gpurun_out/pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py $ARGS > /dev/null 2>&1
