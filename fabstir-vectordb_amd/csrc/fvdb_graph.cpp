@@ -509,7 +509,8 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
   // LDS: visited bitmap over all nodes + fixed tables; the restated candidates heap gets what is left (<= 4096 slots)
   const uint32_t words = (g->n + 31) / 32;
   const uint32_t fixed = build_lds_layout(words, ef_construction, 0).total;
-  const uint32_t lds_max = 160 * 1024;
+  // FVDB_BUILD_LDS_LIMIT: test hook (a small value makes the graph "too large" for the on-chip bitmap)
+  const uint32_t lds_max = getenv("FVDB_BUILD_LDS_LIMIT") ? (uint32_t)atoi(getenv("FVDB_BUILD_LDS_LIMIT")) : 160u * 1024u;
   if (fixed + 512 * 8 > lds_max) FAIL(ctx, FVDB_E_UNSUPPORTED, "device insert: graph too large for the on-chip visited bitmap");
   const uint32_t cand_cap = std::min<uint32_t>(4096, (lds_max - fixed) / 8 & ~1u);
   const BuildLds L = build_lds_layout(words, ef_construction, cand_cap);
@@ -537,7 +538,8 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
   const uint32_t max_rerun = env_rerun >= 0 ? (uint32_t)env_rerun : 0u;
   HIPCHK(ctx, g->d_spec.ensure((size_t)Kmax * kSpecWords * 4));
   HIPCHK(ctx, g->d_elog.ensure((size_t)Kmax * kBuildLayers * kLogCap * 4));
-  HIPCHK(ctx, hipMemsetAsync(g->d_spec.p, 0, (size_t)Kmax * kSpecWords * 4, ctx->stream));  // no stale "usable" flags
+  if (n >= 8)  // (a call that cannot speculate skips this)
+    HIPCHK(ctx, hipMemsetAsync(g->d_spec.p, 0, (size_t)Kmax * kSpecWords * 4, ctx->stream));  // no stale "usable" flags
   FVDB_BUILD_SWITCH(s->dpad, {
     HIPCHK(ctx, hipFuncSetAttribute((const void*)hnsw_insert_commit_kernel<NB_, FULL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
     HIPCHK(ctx, hipFuncSetAttribute((const void*)hnsw_insert_search_kernel<NB_, FULL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));

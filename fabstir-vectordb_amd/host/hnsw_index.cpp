@@ -922,6 +922,11 @@ int HNSWIndex::batch_insert(const uint64_t* ids, const float* v, uint64_t n, uin
       uint32_t nd = 0;
       fvdb_graph_insert_stats st{};
       rc = fvdb_graph_insert_linked(graph_, first + done, m - done, cfg_.ef_construction, insert_mode_, &nd, &st);
+      if (rc == FVDB_E_UNSUPPORTED) {  // e.g. a graph too large for the on-chip visited bitmap: the host algorithm links
+        rc = FVDB_OK;                  // this node (rows patched into HBM), and the question is asked again for the next
+        nd = 0;
+        st.needs_host = 1;
+      }
       if (rc) return finish(rc);
       insert_stats_.n_done += st.n_done;
       insert_stats_.speculated_ok += st.speculated_ok;

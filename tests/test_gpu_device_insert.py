@@ -152,6 +152,27 @@ def test_device_insert_skips_deleted_nodes_and_handles_tall_nodes(fv, ctx):
     same_results(gh.search(q, 10, 50), oh.batch_search(q, 10, 50))
 
 
+def test_graph_too_large_for_the_chip_takes_the_host_algorithm(fv, ctx, monkeypatch):
+    # the device insert keeps the visited bitmap of ALL nodes in LDS; a graph beyond that (about 800K nodes) is linked by
+    # the host algorithm, row patches keep the device copy current, searches stay on the device.  The limit is lowered
+    # through a test hook to get there with a small graph.
+    n, d = 300, 16
+    x = mixture(n, d, n_comp=3, seed=71)
+    ids = np.arange(n, dtype=np.uint64)
+    levels = orc.rng_levels(71, n)
+    gh, oh = fv.HNSWIndex(ctx, 6, 12, 40, seed=71), orc.HNSWIndex(6, 12, 40, seed=71)
+    gh.batch_insert(ids[:200], x[:200], levels[:200])
+    monkeypatch.setenv("FVDB_BUILD_LDS_LIMIT", "4096")
+    gh.batch_insert(ids[200:], x[200:], levels[200:])
+    monkeypatch.delenv("FVDB_BUILD_LDS_LIMIT")
+    oh.batch_insert(ids, x, levels)
+    st = gh.insert_stats()
+    assert st["host_path_inserts"] == 100 and st["n_done"] == 200
+    same_graph(gh, oh)
+    q = mixture(20, d, n_comp=3, seed=72)
+    same_results(gh.search(q, 5, 30), oh.batch_search(q, 5, 30))
+
+
 def test_wide_lists_take_the_host_algorithm(fv, ctx):
     n, d = 150, 16
     x = mixture(n, d, n_comp=3, seed=51)
