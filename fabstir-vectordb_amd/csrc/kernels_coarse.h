@@ -116,6 +116,8 @@ __device__ __forceinline__ float exact_centroid_dist(const float* __restrict__ q
   return sqrtf(acc);
 }
 
+constexpr int kCoarseRegs = 16;  // clusters per lane the register form of the proposal step holds (nlist <= 1024)
+
 // One wave per query.  C = number of candidates proposed by the approximate matrix (<= 64), kc = clusters kept.
 __global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restrict__ A, const float* __restrict__ q,
                                                             const float* __restrict__ c /* [nlist][dpad] */,
@@ -135,6 +137,78 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restr
   WaveTopK<1> prop;
   prop.init();
   uint32_t th = kInf32, tl = kInf32;
+  if (nlist <= 64u * kCoarseRegs && C <= 64 && C >= 1) {
+    // The whole row sits in registers (lane l holds clusters l, l + 64, ...: one coalesced sweep).  The C-th smallest
+    // value is found by bisection on the bit pattern (the values are >= +0: unsigned order is float order), the members
+    // below it and, in cluster-id order, as many equal to it as still fit are compacted into one key per lane and sorted —
+    // the same C keys, in the same order, as inserting the clusters one by one into a sorted list, for a quarter of the
+    // instructions.
+    __shared__ uint32_t s_sel[4][128];
+    uint32_t* sel = s_sel[threadIdx.x >> 6];
+    uint32_t v[kCoarseRegs];
+    uint32_t lo = kInf32, hi = 0;
+#pragma unroll
+    for (int r = 0; r < kCoarseRegs; ++r) {
+      const uint32_t cc = (uint32_t)r * 64u + (uint32_t)lane;
+      v[r] = cc < nlist ? __float_as_uint(arow[cc]) : kInf32;
+      lo = min(lo, v[r]);
+      if (cc < nlist) hi = max(hi, v[r]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo = min(lo, (uint32_t)__shfl_xor(lo, o));
+      hi = max(hi, (uint32_t)__shfl_xor(hi, o));
+    }
+    auto count_le = [&](uint32_t t) {
+      uint32_t cn = 0;
+#pragma unroll
+      for (int r = 0; r < kCoarseRegs; ++r) cn += __popcll(__ballot(v[r] <= t));
+      return cn;
+    };
+    const uint32_t want = min(C, nlist);
+    // smallest t with count(v <= t) >= want: invariant count(lo - 1) < want <= count(hi)
+    uint32_t a = lo, b = hi;
+    while (a < b) {
+      const uint32_t mid = a + ((b - a) >> 1);
+      if (count_le(mid) >= want) b = mid;
+      else a = mid + 1;
+    }
+    const uint32_t t = a;
+    uint32_t n_lt = 0;
+#pragma unroll
+    for (int r = 0; r < kCoarseRegs; ++r) n_lt += __popcll(__ballot(v[r] < t));
+    uint32_t w_lt = 0, w_eq = n_lt;  // write cursors: the values below t first, then the ties in cluster-id order
+#pragma unroll
+    for (int r = 0; r < kCoarseRegs; ++r) {
+      const uint32_t cc = (uint32_t)r * 64u + (uint32_t)lane;
+      const uint64_t ml = __ballot(v[r] < t), me = __ballot(v[r] == t && cc < nlist);
+      const uint64_t below = (1ull << lane) - 1ull;
+      if (v[r] < t) {
+        const uint32_t sl = w_lt + __popcll(ml & below);
+        sel[2 * sl] = v[r];
+        sel[2 * sl + 1] = cc;
+      } else if (v[r] == t && cc < nlist) {
+        const uint32_t sl = w_eq + __popcll(me & below);
+        if (sl < want) {
+          sel[2 * sl] = v[r];
+          sel[2 * sl + 1] = cc;
+        }
+      }
+      w_lt += __popcll(ml);
+      w_eq += __popcll(me);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t shi = kInf32, slo = kInf32;
+    if ((uint32_t)lane < want) {
+      shi = sel[2 * lane];
+      slo = sel[2 * lane + 1];
+    }
+    wave_sort64(shi, slo, lane);
+    prop.hi[0] = shi;
+    prop.lo[0] = slo;
+    prop.kth(C, th, tl);
+  } else
   for (uint32_t c0 = 0; c0 < nlist; c0 += 64) {
     const uint32_t cc = c0 + lane;
     uint32_t chi = kInf32, clo = cc;
