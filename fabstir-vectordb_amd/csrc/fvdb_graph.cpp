@@ -30,7 +30,7 @@ struct fvdb_graph {
   uint32_t entry = 0, top_level = 0;
   bool has_entry = false;
   DBuf d_level, d_deleted, d_ubase, d_adj0, d_adjU, d_dist0, d_distU, d_stamp0, d_stampU, d_state;
-  DBuf d_spec, d_elog, s_patch, s_codes;
+  DBuf d_spec, d_elog, d_chg, s_patch, s_codes;
   HBuf h_state, h_patch;
   bool dist_valid = false;          // dist0 / distU hold the distance of every stored edge
   uint32_t tag = 0;                 // batch counter for the row stamps (never 0)
@@ -523,6 +523,7 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
   st.cursor = 0;
   st.status = 0;
   st.n_valid = st.n_rerun = st.n_stopped = st.rounds = st.consumed = st.scored = st.ties = st.spec_ties = 0;
+  std::memset(st.why, 0, sizeof(st.why));
   rc = push_state(g, st);
   if (rc) return rc;
   // speculation pays once an insert touches a small part of the graph (mode 0 = choose; 1 = never; 2 = always)
@@ -530,14 +531,18 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
   static const int env_k = getenv("FVDB_BUILD_K") ? atoi(getenv("FVDB_BUILD_K")) : 0;
   static const int env_rerun = getenv("FVDB_BUILD_RERUN") ? atoi(getenv("FVDB_BUILD_RERUN")) : -1;
   if (env_mode) mode = env_mode;
-  const uint32_t Kmax = (uint32_t)std::max(1, std::min(env_k > 0 ? env_k : 64, 256));
+  // FVDB_BUILD_STRICT=1: a speculation is dropped when ANY row it expanded changed (round-3 first form; A/B runs)
+  static const uint32_t strict = getenv("FVDB_BUILD_STRICT") ? (uint32_t)atoi(getenv("FVDB_BUILD_STRICT")) : 0u;
+  static const int env_kmax = getenv("FVDB_BUILD_KMAX") ? atoi(getenv("FVDB_BUILD_KMAX")) : 0;
+  const uint32_t Kmax = (uint32_t)std::max(1, std::min(env_k > 0 ? env_k : (env_kmax > 0 ? env_kmax : 128), 256));
   uint32_t K = env_k > 0 ? Kmax : std::min<uint32_t>(16, Kmax);  // adapts to the run length of adopted speculations
   // 0: the commit workgroup adopts speculated searches up to the first one an earlier insert of the batch invalidated,
   // searches that ONE itself (so every launch pair makes progress) and stops; the rest of the batch is speculated again,
   // in parallel, against the graph as it then stands
   const uint32_t max_rerun = env_rerun >= 0 ? (uint32_t)env_rerun : 0u;
   HIPCHK(ctx, g->d_spec.ensure((size_t)Kmax * kSpecWords * 4));
-  HIPCHK(ctx, g->d_elog.ensure((size_t)Kmax * kBuildLayers * kLogCap * 4));
+  HIPCHK(ctx, g->d_elog.ensure((size_t)Kmax * kBuildLayers * kLogWords * 4));
+  HIPCHK(ctx, g->d_chg.ensure((size_t)kChgCap * 4 * 4));
   if (n >= 8)  // (a call that cannot speculate skips this)
     HIPCHK(ctx, hipMemsetAsync(g->d_spec.p, 0, (size_t)Kmax * kSpecWords * 4, ctx->stream));  // no stale "usable" flags
   FVDB_BUILD_SWITCH(s->dpad, {
@@ -565,7 +570,7 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
       const uint32_t tag = g->tag;
       FVDB_BUILD_SWITCH(s->dpad, {
         hipLaunchKernelGGL((hnsw_insert_commit_kernel<NB_, FULL_>), dim3(1), dim3(kBuildThreads), L.total, ctx->stream, v, first, n,
-                           chunk, tag, 0u, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                           chunk, tag, 0u, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, 1u);
       });
       launches = 1;
     } else {
@@ -577,7 +582,7 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
           hipLaunchKernelGGL((hnsw_insert_search_kernel<NB_, FULL_>), dim3(K, kBuildLayers), dim3(kBuildThreads), L.total, ctx->stream, v,
                              first, n, exact_positions, tag, g->d_spec.as<uint32_t>(), g->d_elog.as<uint32_t>());
           hipLaunchKernelGGL((hnsw_insert_commit_kernel<NB_, FULL_>), dim3(1), dim3(kBuildThreads), L.total, ctx->stream, v, first, n, K,
-                             tag, max_rerun, (const uint32_t*)g->d_spec.p, (const uint32_t*)g->d_elog.p);
+                             tag, max_rerun, (const uint32_t*)g->d_spec.p, (const uint32_t*)g->d_elog.p, g->d_chg.as<uint32_t>(), strict);
         });
       }
       launches = 2 * pairs;
@@ -614,6 +619,13 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
             h[5] * us / std::max(1u, done), st.rounds / nn, st.consumed / nn, st.scored / nn);
   }
 #endif
+  if (getenv("FVDB_BUILD_DEBUG"))
+    fprintf(stderr, "[device insert] %u linked, %u adopted, stops %u: entry %u, gave-up %u, order/strict %u, caps %u, added node nearer than a later pop %u, added node inside the final set %u, dropped node matters %u | "
+            "checks %u, touched rows %u\n", done, st.n_valid, st.n_stopped, st.why[1], st.why[2], st.why[3], st.why[4], st.why[5], st.why[6],
+            st.why[9], st.why[7], st.why[8]);
+  if (getenv("FVDB_BUILD_DEBUG"))
+    fprintf(stderr, "[device insert] searches that left the register set: pops tied %u, evictions tied %u, result tied %u, heap overflow %u | speculations given up or restarted %u\n",
+            st.why[11], st.why[12], st.why[13], st.why[14], st.spec_ties);
   g->entry = st.entry;
   g->top_level = st.entry_level;
   g->has_entry = st.has_entry != 0;

@@ -51,10 +51,17 @@ constexpr int kBuildLayers = 16;                 // layers of one node handled o
 constexpr int kNearRegs = 4;                     // sorted `nearest`: 4 registers x 64 lanes => ef <= 256
 constexpr uint32_t kResWords = 2 + 2 * 64;       // per layer: count, pad, 64 nodes, 64 distances
 // one speculated insert in HBM: 64 header words — [1] node, [2] the entry point it started from, [8 + l] the batch tag if
-// layer l's search is usable, [24 + l] expanded rows logged by layer l's search — then the layers' results
-constexpr uint32_t kSpecHdr = 64;
+// layer l's search is usable, [24 + l] expanded rows logged by layer l's search, [40 + l] 1 if that search depended on the
+// ORDER of a neighbour list (equal distances met), [56 + l] the first log entry that belongs to search_layer(ef) (the ones
+// before it are the descent's hops) — then the layers' results
+constexpr uint32_t kSpecHdr = 80;
 constexpr uint32_t kSpecWords = kSpecHdr + kBuildLayers * kResWords;
-constexpr uint32_t kLogCap = 2048;               // expanded rows remembered per speculated insert
+constexpr uint32_t kLogCap = 2048;               // expanded rows remembered per speculated (insert, layer): codes, then bounds
+constexpr uint32_t kLogWords = 5 * kLogCap;          // row codes | bounds W | popped distances P | first-seen masks (lo, hi)
+constexpr uint32_t kChgCap = 8192;               // row changes one commit launch remembers: (row code, node added, node dropped,
+                                                 // its position in the row as the batch found it | 64 if unknown)
+constexpr uint32_t kChkCap = 1024;               // distances one validation may need
+constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kTileRows = 16;               // rows of a wave's product tile
 
 // device-resident state of a graph under construction (one 64-byte record)
@@ -65,7 +72,9 @@ struct BuildState {
   uint32_t n_valid, n_rerun, n_stopped;              // speculation statistics
   uint32_t rounds, consumed, scored, ties;           // search statistics (sums)
   uint32_t spec_ties;                                // speculated searches that met equal distances
-  uint32_t pad[2];
+  uint32_t why[18];  // commit stops by cause: [1] another entry point, [2] a search of the batch gave up (tie / overflow),
+                     // [3] changed row + order-dependent search (or strict), [4] caps, [5] a changed node within the
+                     // bound, [6] ... and that bound was +inf (set never filled); [7] checks made, [8] rows touched
 };
 
 struct BuildView {
@@ -128,7 +137,7 @@ __host__ __device__ inline BuildLds build_lds_layout(uint32_t bitmap_words, uint
 
 // misc words
 enum { MS_NSPEC = 0, MS_NSCORE = 1, MS_DONE = 2, MS_TIE = 3, MS_OVER = 4, MS_CUR = 5, MS_CURD = 6, MS_CONFLICT = 7,
-       MS_NLOG = 8, MS_NC = 9, MS_NN = 10, MS_FNODE = 64, MS_FSLOT = 64 + kSpec, MS_CNT = 64 + 2 * kSpec };
+       MS_NLOG = 8, MS_NC = 9, MS_NN = 10, MS_ORDER = 11, MS_NT = 12, MS_NCHK = 13, MS_NCHG = 14, MS_CHGOVER = 15, MS_SEG0 = 16, MS_FNODE = 64, MS_FSLOT = 64 + kSpec, MS_CNT = 64 + 2 * kSpec };
 
 // ---------------------------------------------------------------------------------------------
 // scoring: RC rows by one wave, one product tile (see score_fixed, kernels_graph_fast.h, for the derivation)
@@ -382,9 +391,13 @@ __device__ __forceinline__ void greedy_layer(const BuildView& g, BuildCtx& c, co
         moved = 1;
       }
       if (lane == 0) {
+        if (moved && __popcll(at) > 1) c.misc[MS_ORDER] = 1;  // two neighbours hold the minimum: the first in LIST ORDER wins
         if (elog) {
           const uint32_t nl = c.misc[MS_NLOG];
-          if (nl < kLogCap) elog[nl] = layer == 0 ? cur : (0x80000000u | (g.ubase[cur] + layer - 1));
+          if (nl < kLogCap) {
+            elog[nl] = layer == 0 ? cur : (0x80000000u | (g.ubase[cur] + layer - 1));
+            elog[kLogCap + nl] = __float_as_uint(nd);  // a neighbour farther than this changes nothing in this hop
+          }
           c.misc[MS_NLOG] = nl + 1;
         }
         c.misc[MS_CUR] = nxt;
@@ -427,13 +440,14 @@ __device__ __forceinline__ void near_write(NearSet& h, uint32_t at, uint32_t nod
     }
 }
 
-// maximum of register r over the slots below ef, and the lane that holds it
-__device__ __forceinline__ void near_reg_max(const NearSet& h, int r, uint32_t ef, int lane, uint32_t& m, uint32_t& ml) {
+// maximum of register r over the slots below ef, the lane that holds it, and how many slots hold it
+__device__ __forceinline__ void near_reg_max(const NearSet& h, int r, uint32_t ef, int lane, uint32_t& m, uint32_t& ml, uint32_t& mc) {
   const bool in = (uint32_t)(r * 64 + lane) < ef;
   const uint32_t v = in ? h.d[r] : 0u;
   m = wave_max_u(v);
   const uint64_t at = __ballot(in && v == m);
   ml = at ? (uint32_t)__builtin_ctzll(at) : 0u;
+  mc = (uint32_t)__popcll(at);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -466,9 +480,9 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
   // non-EXACT: the maximum of the set.  While it fills: a running maximum.  Once full: per-register maxima (rm, lane
   // rl), the set's maximum is the largest of them (register wr) — an admission then re-reduces ONE register.
   uint32_t worst = 0, wr = 0;
-  uint32_t rm[kNearRegs], rl[kNearRegs];
+  uint32_t rm[kNearRegs], rl[kNearRegs], rc[kNearRegs];
 #pragma unroll
-  for (int r = 0; r < kNearRegs; ++r) rm[r] = rl[r] = 0;
+  for (int r = 0; r < kNearRegs; ++r) rm[r] = rl[r] = rc[r] = 0;
   auto pick_worst = [&]() {
     worst = rm[0];
     wr = 0;
@@ -481,6 +495,7 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
   };
   if (c.wave == 0) {
     if (lane == 0) {
+      c.misc[MS_SEG0] = c.misc[MS_NLOG];
       atomicOr(&c.bitmap[start >> 5], 1u << (start & 31));
       c.misc[MS_NSCORE] = 0;
       c.misc[MS_TIE] = 0;
@@ -496,17 +511,27 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
       if (ef == 1) {
         rm[0] = worst;
         rl[0] = 0;
+        rc[0] = 1;
       }
     }
   }
   uint32_t rounds = 0, consumed = 0, scored = 0;
+  // Equal distances inside the heaps (set form only; wave 0).  BinaryHeap's layout decides between equal keys only when
+  // two of them are at the top of a heap at once, and even then the choice is often without consequence:
+  //  * `amb`: two members shared the maximum when one had to leave.  Either may be the one that left; as long as the one
+  //    that stayed is never popped — it leaves too, or sits past the m entries select_neighbors reads — both choices run
+  //    the same search.  (Later maxima are smaller, nothing is admitted at the old maximum: one value covers it.)
+  //  * `twin_d`, `twin_left`: two candidates shared the minimum at a pop.  If neither expansion admits anything nearer
+  //    than the pair, the two are expanded back to back in either order and leave the same set behind.
+  uint32_t amb = 0xFFFFFFFFu, twin_d = 0xFFFFFFFFu, twin_left = 0;
   for (;;) {
     BSTAMP(t0);
     if (c.wave == 0) {
       bool tie = false, over = false, finished = false;
+      uint32_t tie_why = 0;
       // ---- the reference's loop, out of the table ----
       for (;;) {
-        uint32_t node, slot = 0;
+        uint32_t node, slot = 0, popd = 0;
         if (EXACT) {
           if (nC == 0) {
             finished = true;
@@ -518,6 +543,7 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
             break;
           }
           node = top.node;
+          popd = __float_as_uint(top.d);
         } else {
           // candidates.pop(): the nearest member not yet expanded; none left = the reference's exits (:498-501)
           uint32_t key[kNearRegs], m = 0xFFFFFFFFu;
@@ -531,14 +557,27 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
             finished = true;
             break;
           }
+          popd = mv;
           node = 0;
+          uint32_t holders = 0;
 #pragma unroll
           for (int r = kNearRegs - 1; r >= 0; --r) {
             const uint64_t at = __ballot(key[r] == mv);
+            holders += (uint32_t)__popcll(at);
             if (at) {
               slot = (uint32_t)r * 64u + (uint32_t)__builtin_ctzll(at);
               node = __builtin_amdgcn_readlane(h.n[r], slot & 63);
             }
+          }
+          // two candidates share the smallest distance: which one BinaryHeap::pop returns is its layout's business
+          if (holders > 2 || mv == amb || (twin_left != 0 && (mv != twin_d || holders != twin_left))) {
+            tie = true;
+            tie_why = 1;
+            break;
+          }
+          if (holders == 2 && twin_left == 0) {
+            twin_d = mv;
+            twin_left = 2;
           }
         }
         const uint64_t hit = __ballot(slot_node == node);
@@ -553,11 +592,6 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
             if ((slot >> 6) == (uint32_t)r) h.n[r] = writelane_u(node | 0x80000000u, slot & 63, h.n[r]);
         }
         consumed += 1;
-        if (elog && lane == 0) {
-          const uint32_t nl = c.misc[MS_NLOG];
-          if (nl < kLogCap) elog[nl] = layer == 0 ? node : (0x80000000u | (g.ubase[node] + layer - 1));
-          c.misc[MS_NLOG] = nl + 1;
-        }
         const uint32_t cnt = c.misc[MS_CNT + p];
         uint32_t nb = 0;
         bool keep = false;
@@ -572,6 +606,7 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
           if (keep) db = __float_as_uint(c.dist[p * 64 + lane]);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint64_t seen = __ballot(keep);
         // admission (:517-531) in list order; `worst` only shrinks while they are applied
         if (EXACT) worst = __float_as_uint(-c.near[0].d);
         uint64_t todo = __ballot(keep && (nN < ef || db < worst));
@@ -580,6 +615,11 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
           todo &= todo - 1;
           const uint32_t di = __builtin_amdgcn_readlane(db, i);
           if (!(nN < ef || di < worst)) continue;
+          if (!EXACT && twin_left != 0 && di < twin_d) {  // the pair is not expanded back to back: the order matters
+            tie = true;
+            tie_why = 1;
+            break;
+          }
           const uint32_t ni = __builtin_amdgcn_readlane(nb, i);
 #ifdef FVDB_BUILD_STAMPS
           if (threadIdx.x == 0 && g.dbg) atomicAdd(g.dbg + 8, 1ull);
@@ -595,32 +635,43 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
             if (nN > ef) (void)lds_pop_parallel(c.near, nN, lane);
             worst = __float_as_uint(-c.near[0].d);
           } else {
-            bool eq = false;
-#pragma unroll
-            for (int r = 0; r < kNearRegs; ++r) eq = eq || h.d[r] == di;
-            if (__ballot(eq)) {  // equal distances inside the heaps: their order is the reference's heap layout
-              tie = true;
-              break;
-            }
             if (nN < ef) {
               near_write(h, nN, ni, di);
               nN += 1;
               worst = max(worst, di);
               if (nN == ef) {  // full from here on: per-register maxima
 #pragma unroll
-                for (int r = 0; r < kNearRegs; ++r) near_reg_max(h, r, ef, lane, rm[r], rl[r]);
+                for (int r = 0; r < kNearRegs; ++r) near_reg_max(h, r, ef, lane, rm[r], rl[r], rc[r]);
                 pick_worst();
               }
             } else {  // the maximum leaves (nearest.pop(), :528-530), the newcomer takes its slot
+              uint32_t holders = 0;
+#pragma unroll
+              for (int r = 0; r < kNearRegs; ++r) holders += rm[r] == worst ? rc[r] : 0u;
+              if (holders > 1) amb = worst;  // two members share the largest distance: which one leaves is the layout's business
               near_write(h, wr * 64u + rl[wr], ni, di);
 #pragma unroll
               for (int r = 0; r < kNearRegs; ++r)
-                if (wr == (uint32_t)r) near_reg_max(h, r, ef, lane, rm[r], rl[r]);
+                if (wr == (uint32_t)r) near_reg_max(h, r, ef, lane, rm[r], rl[r], rc[r]);
               pick_worst();
             }
           }
         }
         if (tie || over) break;
+        // the expanded row and the bound its neighbours met: with `nearest` full, a neighbour farther than the maximum
+        // left by this expansion was (or would be) turned away — whether the row holds it or not changes nothing
+        if (elog && lane == 0) {
+          const uint32_t nl = c.misc[MS_NLOG];
+          if (nl < kLogCap) {
+            elog[nl] = layer == 0 ? node : (0x80000000u | (g.ubase[node] + layer - 1));
+            elog[kLogCap + nl] = nN >= ef ? worst : 0x7F800000u;
+            elog[2 * kLogCap + nl] = popd | (twin_left != 0 ? 0x80000000u : 0u);  // flag: see validate_speculation
+            elog[3 * kLogCap + nl] = (uint32_t)seen;  // list positions whose node was met for the first time here
+            elog[4 * kLogCap + nl] = (uint32_t)(seen >> 32);
+          }
+          c.misc[MS_NLOG] = nl + 1;
+        }
+        if (twin_left != 0) twin_left -= 1;
       }
       BSTAMP(ta);
       BSTAMP_ADD(g, 6, t0, ta);
@@ -709,7 +760,7 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
       if (lane == 0) {
         c.misc[MS_NSPEC] = nf;
         c.misc[MS_NSCORE] = 0;
-        if (tie) c.misc[MS_TIE] = 1;
+        if (tie) c.misc[MS_TIE] = tie_why;
         if (over) c.misc[MS_OVER] = 1;
       }
     }
@@ -731,6 +782,7 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
     scored += U;
   }
   const bool failed = (c.misc[MS_TIE] | c.misc[MS_OVER]) != 0;
+  if (failed && threadIdx.x == 0) atomicAdd(&g.state->why[c.misc[MS_OVER] ? 14 : 10 + min(c.misc[MS_TIE], 2u)], 1u);
   __syncthreads();
   if (threadIdx.x == 0 && stat) {
     stat[0] += rounds;
@@ -746,7 +798,10 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
       for (int r = 0; r < kNearRegs; ++r)
         if ((uint32_t)(r * 64 + lane) < nN) c.near[r * 64 + lane] = HItem{h.n[r] & 0x7FFFFFFFu, -__uint_as_float(h.d[r])};
     }
-    if (lane == 0) c.misc[MS_NN] = nN;
+    if (lane == 0) {
+      c.misc[MS_NN] = nN;
+      if (!EXACT && worst == amb && nN <= (layer == 0 ? g.M0 : g.M) + 1) c.misc[MS_TIE] = 3;
+    }
   }
   __syncthreads();
   const uint32_t nn = c.misc[MS_NN];
@@ -754,17 +809,26 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
     const HItem me = c.near[i];
     const float md = -me.d;
     uint32_t rank = 0;
+    bool twin = false;
     for (uint32_t j = 0; j < nn; ++j) {
       const float dj = -c.near[j].d;
       rank += (dj < md || (dj == md && j < i)) ? 1u : 0u;
+      twin = twin || (dj == md && j != i);
     }
     if (rank < 64) {
       out[2 + rank] = me.node;
       out[2 + 64 + rank] = __float_as_uint(md);
     }
+    // the stable sort leaves equal distances in the heap array's order, which the set does not have
+    // (only the first m entries are ever used: select_neighbors)
+    if (!EXACT && twin && rank <= (layer == 0 ? g.M0 : g.M)) c.misc[MS_TIE] = 3;
   }
   if (threadIdx.x == 0) out[0] = min(nn, 64u);
   __syncthreads();
+  if (!EXACT && c.misc[MS_TIE] != 0) {
+    if (threadIdx.x == 0) atomicAdd(&g.state->why[10 + 3], 1u);
+    return false;
+  }
   return true;
 }
 
@@ -781,6 +845,7 @@ __device__ __forceinline__ bool ef_search(const BuildView& g, BuildCtx& c, const
     if (threadIdx.x == 0) c.misc[MS_NLOG] = log0;  // the aborted attempt expanded a prefix of what the exact run expands
     __syncthreads();
   }
+  if (threadIdx.x == 0) c.misc[MS_ORDER] = 1;  // heaps with equal keys: the outcome depends on the order of the lists
   return ef_search_layer<NB, FULL, true>(g, c, q2, layer, start, start_d, elog, stat);
 }
 
@@ -804,6 +869,7 @@ __device__ __forceinline__ bool insert_searches(const BuildView& g, BuildCtx& c,
   if (threadIdx.x == 0) {
     c.misc[MS_NLOG] = 0;
     c.misc[MS_NSCORE] = 0;
+    c.misc[MS_ORDER] = 0;
   }
   // d(q, entry) (:277-281)
   if (c.wave == 0) {
@@ -833,8 +899,22 @@ __device__ __forceinline__ bool insert_searches(const BuildView& g, BuildCtx& c,
 // ---------------------------------------------------------------------------------------------
 // Links of one insert (:293-362) from res[]: the new node's rows, the back-links, the prunes.  `tag`: this batch.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void insert_links(const BuildView& g, BuildCtx& c, uint32_t node, uint32_t level, uint32_t tag) {
+// `chg` (commit of a speculated batch): every stamped row change is remembered as (row code, node added, node dropped) so
+// that later speculations of the batch can tell whether the change matters to them (validate_speculation).
+__device__ __forceinline__ void insert_links(const BuildView& g, BuildCtx& c, uint32_t node, uint32_t level, uint32_t tag, uint32_t* chg) {
   const int lane = c.lane;
+  auto record = [&](uint32_t code, uint32_t added, uint32_t dropped, uint32_t pos) {  // one lane
+    if (!chg) return;
+    const uint32_t at = atomicAdd(&c.misc[MS_NCHG], 1u);
+    if (at < kChgCap) {
+      chg[4 * at] = code;
+      chg[4 * at + 1] = added;
+      chg[4 * at + 2] = dropped;
+      chg[4 * at + 3] = pos;
+    } else {
+      c.misc[MS_CHGOVER] = 1;
+    }
+  };
   for (uint32_t lc = 0; lc <= level; ++lc) {
     const uint32_t* r = c.res + lc * kResWords;
     const uint32_t m = lc == 0 ? g.M0 : g.M;
@@ -862,6 +942,7 @@ __device__ __forceinline__ void insert_links(const BuildView& g, BuildCtx& c, ui
           adjd[at + 1 + k] = dn;
           adj[at] = k + 1;
           (lc == 0 ? g.stamp0[nbv] : g.stampU[g.ubase[nbv] + lc - 1]) = tag;
+          record(lc == 0 ? nbv : (0x80000000u | (g.ubase[nbv] + lc - 1)), node, kNone, 64u);
         }
         continue;
       }
@@ -885,13 +966,169 @@ __device__ __forceinline__ void insert_links(const BuildView& g, BuildCtx& c, ui
           adj[at + 1 + rank] = e_n;
           adjd[at + 1 + rank] = e_d;
         }
+        const uint32_t added = __builtin_amdgcn_readlane(rank, k) < m ? node : kNone;  // lane k holds the new node
+        uint64_t out = __ballot((uint32_t)lane < k && rank >= m);
+        uint32_t* stamp = lc == 0 ? &g.stamp0[nbv] : &g.stampU[g.ubase[nbv] + lc - 1];
+        // the row as this batch's speculations read it: positions are still theirs if nobody of the batch rewrote it
+        const bool untouched = __builtin_amdgcn_readfirstlane(*stamp) != tag;
         if (lane == 0) {
           adj[at] = min(tot, m);
-          (lc == 0 ? g.stamp0[nbv] : g.stampU[g.ubase[nbv] + lc - 1]) = tag;
+          *stamp = tag;
+        }
+        const uint32_t code = lc == 0 ? nbv : (0x80000000u | (g.ubase[nbv] + lc - 1));
+        bool first = true;
+        do {  // (members only moved: nothing to remember — a search that depends on list order takes the stamp alone)
+          uint32_t dropped = kNone, pos = 64;
+          if (out) {
+            pos = (uint32_t)__builtin_ctzll(out);
+            dropped = __builtin_amdgcn_readlane(e_n, pos);
+            if (!untouched) pos = 64;
+            out &= out - 1;
+          }
+          if (lane == 0 && (dropped != kNone || (first && added != kNone))) record(code, first ? added : kNone, dropped, pos);
+          first = false;
+        } while (out);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Is a search speculated against an older graph still the search the reference would run now?
+//
+// While no two distances inside the heaps are equal, search_layer is a function of the neighbour SETS of the rows it
+// expands: with A = everything admitted so far, `nearest` is the ef smallest of A, the next pop is its nearest member
+// not yet expanded, the search ends when there is none (`visited` only spares work: what was turned away once is
+// farther than every later maximum).  The speculated search logged, per expansion t: the row e_t, the distance P_t of
+// the candidate popped, and W_t = the maximum of `nearest` after the expansion (+inf while it is not full).
+//
+// Let an earlier insert of this batch have added x to (or dropped x from) row e_k.  With x admitted at step k the set is
+// the same except that x displaces the current maximum; that lasts until the first t_out >= k with W_t < d(q, x), when
+// x itself is the element that leaves.  In between, both runs pop the same candidate as long as that candidate is nearer
+// than x (the displaced maximum and x are both farther, so neither is the pop).  Hence, if
+//     t_out exists   and   P_t < d(q, x) for every k < t <= t_out,
+// every pop, every expansion and the set after t_out are the same with or without x — by induction over all such x
+// (several at once displace the top few, which are all farther than the pop; a dropped x that was in the set is the
+// mirror image: the logged run is the one "with x", and the condition says it never expanded x and let it go).  A greedy
+// hop (ef = 1) is the case t_out = k: the hop ended on distance W_k and x is farther.  Anything else is a conflict:
+// x within the final set, x nearer than a later pop, ANY change to an expanded row when the search met equal distances
+// (list order then matters: the speculation says so in its header), and any change at all in `strict` mode.
+//
+// Returns 0 (adopt) or the cause.  Uses the searches' scratch (dist / nbr / slist / cand), idle between two inserts.
+// ---------------------------------------------------------------------------------------------
+template <int NB, bool FULL>
+__device__ __forceinline__ uint32_t validate_speculation(const BuildView& g, BuildCtx& c, uint32_t node, uint32_t level, uint32_t tag,
+                                                         const uint32_t* __restrict__ sp, const uint32_t* __restrict__ elog, const uint32_t* chg,
+                                                         bool strict) {
+  uint32_t* t_code = (uint32_t*)c.dist;            // touched rows of the log: code, position (layer * kLogCap + entry)
+  uint32_t* t_ref = (uint32_t*)c.dist + kChkCap;
+  uint32_t* k_ref = (uint32_t*)c.cand;             // checks: node in nbr[i], log position here (cand_cap >= 512 items)
+  if (threadIdx.x == 0) {
+    c.misc[MS_CONFLICT] = 0;
+    c.misc[MS_NT] = 0;
+    c.misc[MS_NCHK] = 0;
+  }
+  __syncthreads();
+  const bool coarse = strict || chg == nullptr || c.misc[MS_CHGOVER] != 0;
+  for (uint32_t l = 0; l <= level; ++l) {
+    const uint32_t nlog = sp[24 + l];
+    const bool order = sp[40 + l] != 0;
+    const uint32_t* el = elog + (size_t)l * kLogWords;
+    for (uint32_t i = threadIdx.x; i < nlog; i += kBuildThreads) {
+      const uint32_t code = el[i];
+      const uint32_t sv = (code >> 31) ? g.stampU[code & 0x7FFFFFFFu] : g.stamp0[code];
+      if (sv != tag) continue;
+      if (coarse || order) {
+        c.misc[MS_CONFLICT] = 3;
+      } else {
+        const uint32_t t = atomicAdd(&c.misc[MS_NT], 1u);
+        if (t < kChkCap) {
+          t_code[t] = code;
+          t_ref[t] = l * kLogCap + i;
+        } else {
+          c.misc[MS_CONFLICT] = 4;
         }
       }
     }
   }
+  __syncthreads();
+  if (c.misc[MS_CONFLICT]) return c.misc[MS_CONFLICT];
+  const uint32_t nt = c.misc[MS_NT];
+  if (nt == 0) return 0;
+  // the changes those rows saw -> (node, log position) checks
+  const uint32_t nrec = min(c.misc[MS_NCHG], kChgCap);
+  for (uint32_t r = threadIdx.x; r < nrec; r += kBuildThreads) {
+    const uint32_t code = chg[4 * r];
+    for (uint32_t t = 0; t < nt; ++t) {
+      if (t_code[t] != code) continue;  // (no early exit: the descent and the layer's own search may both have expanded the row)
+      for (int e = 1; e <= 2; ++e) {
+        const uint32_t x = chg[4 * r + e];
+        if (x == kNone) continue;
+        if (e == 2) {
+          // a dropped node the search had met before it came to this row (or never scored: soft-deleted) was skipped
+          // there: the row without it reads the same.  Known when the change was the batch's first to the row.
+          const uint32_t pos = chg[4 * r + 3], ref = t_ref[t];
+          const uint32_t l = ref / kLogCap, k = ref % kLogCap;
+          if (pos < 64 && k >= sp[56 + l]) {
+            const uint32_t* el = elog + (size_t)l * kLogWords;
+            const uint32_t w = el[(pos < 32 ? 3 : 4) * kLogCap + k];
+            if (((w >> (pos & 31)) & 1u) == 0) continue;
+          }
+        }
+        const uint32_t k = atomicAdd(&c.misc[MS_NCHK], 1u);
+        if (k < kChkCap) {
+          c.nbr[k] = x;
+          c.slist[k] = (uint16_t)k;
+          k_ref[k] = t_ref[t] | (e == 2 ? 0x80000000u : 0u);
+        } else {
+          c.misc[MS_CONFLICT] = 4;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (c.misc[MS_CONFLICT]) return c.misc[MS_CONFLICT];
+  const uint32_t nchk = c.misc[MS_NCHK];
+  if (nchk == 0) return 0;  // the rows were only re-ordered
+  float2 q2[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const uint32_t j = (uint32_t)b * 128u + 2u * (uint32_t)c.lane;
+    q2[b] = j < g.dpad ? *(const float2*)(g.rows + (size_t)node * g.dpad + j) : make_float2(0.0f, 0.0f);
+  }
+  score_lists<NB, FULL>(g, c, q2, nchk);  // dist[i] overwrites the touched-row list, which is no longer needed
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < nchk; i += kBuildThreads) {
+    const float dx = c.dist[i];
+    const uint32_t ref = k_ref[i] & 0x7FFFFFFFu;
+    const uint32_t l = ref / kLogCap, k = ref % kLogCap;
+    const uint32_t* el = elog + (size_t)l * kLogWords;
+    const uint32_t nlog = sp[24 + l], seg0 = sp[56 + l];
+    uint32_t why = 6;  // the log ends with x still inside the set (or the set never filled)
+    if (k < seg0) {
+      why = __uint_as_float(el[kLogCap + k]) < dx ? 0u : 5u;
+    } else {
+      for (uint32_t t = k; t < nlog; ++t) {
+        const uint32_t pt = el[2 * kLogCap + t];
+        // (a pop that shared its distance with another: the pair's order is immaterial only while neither expansion
+        // admits anything nearer than the pair — x, met at such an expansion, has to be farther than that pop as well)
+        if ((t > k || (pt >> 31)) && !(__uint_as_float(pt & 0x7FFFFFFFu) < dx)) {
+          why = 5;  // a later pop is not nearer than x
+          break;
+        }
+        if (__uint_as_float(el[kLogCap + t]) < dx) {
+          why = 0;
+          break;
+        }
+      }
+    }
+    if (why && (k_ref[i] >> 31)) why = 9;
+    if (why) atomicMax(&c.misc[MS_CONFLICT], why);
+  }
+  __syncthreads();
+  const uint32_t why = c.misc[MS_CONFLICT];
+  __syncthreads();
+  return why;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -903,7 +1140,7 @@ __device__ __forceinline__ void insert_links(const BuildView& g, BuildCtx& c, ui
 template <int NB, bool FULL>
 __global__ __launch_bounds__(kBuildThreads, 1) void hnsw_insert_search_kernel(const BuildView g, uint32_t first, uint32_t n, uint32_t exact_positions,
                                                                               uint32_t tag, uint32_t* __restrict__ spec /* [grid.x][kSpecWords] */,
-                                                                              uint32_t* __restrict__ elogs /* [grid.x][kBuildLayers][kLogCap] */) {
+                                                                              uint32_t* __restrict__ elogs /* [grid.x][kBuildLayers][kLogWords] */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_b[];
   const uint32_t layer = blockIdx.y;
   const BuildState st = *g.state;
@@ -915,7 +1152,7 @@ __global__ __launch_bounds__(kBuildThreads, 1) void hnsw_insert_search_kernel(co
   const BuildLds L = build_lds_layout(g.bitmap_words, g.ef, g.cand_cap);
   BuildCtx c = build_ctx(lds_b, L);
   uint32_t* out = spec + (size_t)blockIdx.x * kSpecWords;
-  uint32_t* elog = elogs + ((size_t)blockIdx.x * kBuildLayers + layer) * kLogCap;
+  uint32_t* elog = elogs + ((size_t)blockIdx.x * kBuildLayers + layer) * kLogWords;
   // a search that meets equal distances starts again with the restated heaps — twice the time: only the first few
   // speculations of a batch, the ones most likely to be adopted, do that; the others are left to the next batch
   // (`exact_positions`: the host raises it to the whole batch on data where ties are the rule, e.g. duplicate vectors)
@@ -929,6 +1166,8 @@ __global__ __launch_bounds__(kBuildThreads, 1) void hnsw_insert_search_kernel(co
     out[2] = st.entry;
     out[8 + layer] = (ok && nlog <= kLogCap) ? tag : 0u;
     out[24 + layer] = nlog;
+    out[40 + layer] = c.misc[MS_ORDER];
+    out[56 + layer] = c.misc[MS_SEG0];
   }
   const uint32_t* r = c.res + layer * kResWords;
   for (uint32_t i = threadIdx.x; i < kResWords; i += kBuildThreads) out[kSpecHdr + layer * kResWords + i] = r[i];
@@ -942,15 +1181,21 @@ template <int NB, bool FULL>
 __global__ __launch_bounds__(kBuildThreads, 1) void hnsw_insert_commit_kernel(const BuildView g, uint32_t first, uint32_t n, uint32_t count,
                                                                               uint32_t tag, uint32_t max_rerun,
                                                                               const uint32_t* __restrict__ spec,
-                                                                              const uint32_t* __restrict__ elogs) {
+                                                                              const uint32_t* __restrict__ elogs, uint32_t* __restrict__ chg,
+                                                                              uint32_t strict) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_b[];
   const BuildLds L = build_lds_layout(g.bitmap_words, g.ef, g.cand_cap);
   BuildCtx c = build_ctx(lds_b, L);
   BuildState st = *g.state;
   if (st.status != 0) return;
+  if (threadIdx.x == 0) {
+    c.misc[MS_NCHG] = 0;
+    c.misc[MS_CHGOVER] = 0;
+  }
+  __syncthreads();
   uint32_t reruns = 0;
   uint32_t stat[4] = {0, 0, 0, 0};
-  uint32_t n_valid = 0, n_rerun = 0, stopped = 0;
+  uint32_t n_valid = 0, n_rerun = 0, stopped = 0, why_stop = 0, n_chk = 0, n_touch = 0;
   uint32_t done = 0;
   for (uint32_t b = 0; b < count; ++b) {
     const uint32_t idx = st.cursor + b;
@@ -979,28 +1224,19 @@ __global__ __launch_bounds__(kBuildThreads, 1) void hnsw_insert_commit_kernel(co
       const uint32_t* sp = spec + (size_t)b * kSpecWords;
       bool usable = sp[1] == node && sp[2] == st.entry;
       for (uint32_t l = 0; l <= level; ++l) usable = usable && sp[8 + l] == tag;
+      uint32_t why = sp[1] == node && sp[2] == st.entry ? 2u : 1u;
       if (usable) {
-        if (threadIdx.x == 0) c.misc[MS_CONFLICT] = 0;
-        __syncthreads();
-        bool bad = false;
-        for (uint32_t l = 0; l <= level; ++l) {
-          const uint32_t nlog = sp[24 + l];
-          const uint32_t* el = elogs + ((size_t)b * kBuildLayers + l) * kLogCap;
-          for (uint32_t i = threadIdx.x; i < nlog; i += kBuildThreads) {
-            const uint32_t code = el[i];
-            const uint32_t sv = (code >> 31) ? g.stampU[code & 0x7FFFFFFFu] : g.stamp0[code];
-            bad = bad || sv == tag;
-          }
-        }
-        if (bad) c.misc[MS_CONFLICT] = 1;
-        __syncthreads();
-        have = c.misc[MS_CONFLICT] == 0;
+        why = validate_speculation<NB, FULL>(g, c, node, level, tag, sp, elogs + (size_t)b * kBuildLayers * kLogWords, chg, strict != 0);
+        have = why == 0;
+        n_chk += c.misc[MS_NCHK];
+        n_touch += c.misc[MS_NT];
         if (have) {
           const uint32_t words = (level + 1) * kResWords;
           for (uint32_t i = threadIdx.x; i < words; i += kBuildThreads) c.res[i] = sp[kSpecHdr + i];
         }
         __syncthreads();
       }
+      if (!have) why_stop = why;
     }
     if (have) {
       n_valid += 1;
@@ -1020,7 +1256,7 @@ __global__ __launch_bounds__(kBuildThreads, 1) void hnsw_insert_commit_kernel(co
       BSTAMP_ADD(g, 4, ts0, ts1);
     }
     BSTAMP(tl0);
-    insert_links(g, c, node, level, tag);
+    insert_links(g, c, node, level, tag, spec ? chg : nullptr);
     BSTAMP(tl1);
     BSTAMP_ADD(g, 5, tl0, tl1);
     st.n_linked += 1;
@@ -1043,6 +1279,9 @@ __global__ __launch_bounds__(kBuildThreads, 1) void hnsw_insert_commit_kernel(co
     o->n_valid += n_valid;
     o->n_rerun += n_rerun;
     o->n_stopped += stopped;
+    if (stopped) o->why[why_stop < 10 ? why_stop : 0] += 1;
+    o->why[7] += n_chk;
+    o->why[8] += n_touch;
     o->rounds += stat[0];
     o->consumed += stat[1];
     o->scored += stat[2];

@@ -73,6 +73,30 @@ def test_device_insert_builds_the_oracles_graph(fv, ctx, n, d, M, M0, efc, seed,
         same_results(gh.search(q, 10, 50), oh.batch_search(q, 10, 50))
 
 
+@pytest.mark.parametrize("n,d,M,M0,efc,n_comp,seed", [
+    (6000, 12, 6, 12, 40, 16, 81),      # low dimension: the inserts of a batch land in each other's neighbourhoods all the time
+    (4000, 384, 16, 32, 200, 4096, 82),  # near-isotropic rows (SURVEY §8d's mixture): every node is "about as far" as any other
+    (5000, 24, 8, 16, 300, 8, 83),      # ef_construction above the register set: restated heaps, order-dependent searches
+])
+def test_speculated_batches_adopt_only_what_the_reference_would_compute(fv, ctx, n, d, M, M0, efc, n_comp, seed):
+    # speculation from the first node on (mode 2), long batches: a speculated search is adopted although rows it expanded
+    # were changed by earlier inserts of its batch when every node added to / dropped from those rows is provably
+    # irrelevant to it (validate_speculation, kernels_graph_build.h) — the graph must still be the oracle's node for node
+    x = mixture(n, d, n_comp=n_comp, seed=seed)
+    ids = np.arange(n, dtype=np.uint64)
+    levels = orc.rng_levels(seed, n)
+    gh, oh = fv.HNSWIndex(ctx, M, M0, efc, seed=seed), orc.HNSWIndex(M, M0, efc, seed=seed)
+    gh.set_device_insert(True, 2)
+    assert gh.batch_insert(ids, x, levels) == (n, 0)
+    oh.batch_insert(ids, x, levels)
+    st = gh.insert_stats()
+    # (a restated `candidates` heap that outgrows its LDS slots sends that one insert through the host algorithm)
+    assert st["host_path_inserts"] <= 4 and st["speculated_ok"] > n // 4
+    print(f"[speculation] n {n} d {d} ef {efc}: {st['speculated_ok']} adopted, {st['commit_stops']} stops, "
+          f"{st['launches'] // 2} batches")
+    same_graph(gh, oh)
+
+
 def test_device_insert_equals_host_algorithm_and_continues_after_it(fv, ctx):
     # half the nodes by the host algorithm (per-hop GPU scoring), the rest on the device, then one more host insert:
     # each switch hands the graph across (whole install once, then row patches / pulls), the result is the oracle's
