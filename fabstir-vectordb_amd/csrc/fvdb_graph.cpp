@@ -534,6 +534,8 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
   // FVDB_BUILD_STRICT=1: a speculation is dropped when ANY row it expanded changed (round-3 first form; A/B runs)
   static const uint32_t strict = getenv("FVDB_BUILD_STRICT") ? (uint32_t)atoi(getenv("FVDB_BUILD_STRICT")) : 0u;
   static const int env_kmax = getenv("FVDB_BUILD_KMAX") ? atoi(getenv("FVDB_BUILD_KMAX")) : 0;
+  // below this many nodes every insert lands in every other's neighbourhood: one at a time, no speculation
+  static const uint32_t seq_below = getenv("FVDB_BUILD_SEQ_BELOW") ? (uint32_t)atoi(getenv("FVDB_BUILD_SEQ_BELOW")) : 256u;
   const uint32_t Kmax = (uint32_t)std::max(1, std::min(env_k > 0 ? env_k : (env_kmax > 0 ? env_kmax : 128), 256));
   uint32_t K = env_k > 0 ? Kmax : std::min<uint32_t>(16, Kmax);  // adapts to the run length of adopted speculations
   // 0: the commit workgroup adopts speculated searches up to the first one an earlier insert of the batch invalidated,
@@ -561,11 +563,11 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
   uint32_t exact_positions = 4;  // speculated searches of a batch that may start again with the restated heaps on a tie
   uint32_t ties_seen = 0;
   while (done < n) {
-    const bool speculate = mode == 2 || (mode == 0 && (uint64_t)first + done >= 1000 && n - done >= 8);
+    const bool speculate = mode == 2 || (mode == 0 && (uint64_t)first + done >= seq_below && n - done >= 8);
     uint32_t launches = 0;
     if (!speculate) {
       uint32_t chunk = std::min<uint32_t>(n - done, 2048);  // bounds one launch to a fraction of a second
-      if (mode == 0 && (uint64_t)first + done < 1000) chunk = std::min<uint32_t>(chunk, 1000 - (first + done));
+      if (mode == 0 && (uint64_t)first + done < seq_below) chunk = std::min<uint32_t>(chunk, seq_below - (first + done));
       g->tag += 1;
       const uint32_t tag = g->tag;
       FVDB_BUILD_SWITCH(s->dpad, {
@@ -626,6 +628,8 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
   if (getenv("FVDB_BUILD_DEBUG"))
     fprintf(stderr, "[device insert] searches that left the register set: pops tied %u, evictions tied %u, result tied %u, heap overflow %u | speculations given up or restarted %u\n",
             st.why[11], st.why[12], st.why[13], st.why[14], st.spec_ties);
+  if (getenv("FVDB_BUILD_DEBUG"))
+    fprintf(stderr, "[device insert] second looks: overlapping %u, nodes the popped newcomer would bring in %u, later pop is the maximum %u\n", st.why[15], st.why[16], st.why[17]);
   g->entry = st.entry;
   g->top_level = st.entry_level;
   g->has_entry = st.has_entry != 0;

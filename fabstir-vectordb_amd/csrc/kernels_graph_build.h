@@ -16,11 +16,16 @@
 //    stops at the first candidate whose list is not in the table (an admission moved a new node to the front) and
 //    the next round fetches again.  Scoring a row the serial algorithm would never have scored has no effect.
 //
-//  * `nearest` is a sorted array across the registers of wave 0 (4 registers x 64 lanes, ef <= 256) and `candidates`
-//    is implicit (the unexpanded members of `nearest`): identical to the reference's two BinaryHeaps while all
-//    distances inside them are distinct (the argument is in kernels_graph_fast.h).  Every admission checks for an
-//    equal distance already present; at the first one the layer's search starts again with the reference's heaps
-//    restated in LDS (lds_push_parallel / lds_pop_parallel, kernels_graph.h), so ties resolve as in the reference.
+//  * `nearest` is a SET across the registers of wave 0 (4 registers x 64 lanes, ef <= 256) and `candidates` is implicit
+//    (the unexpanded members of `nearest`): identical to the reference's two BinaryHeaps as long as the heaps' LAYOUT
+//    never decides anything.  It decides only between equal keys at the top of a heap.  Two members sharing the maximum
+//    when one has to leave: either may go — the search is the same unless the one that stayed is popped later or ends up
+//    among the m entries select_neighbors reads (`amb`).  Two candidates sharing the minimum at a pop: if neither
+//    expansion admits anything nearer, they are expanded back to back in either order (`twin_*`).  Equal distances in
+//    the first m entries of the result: the stable sort would keep the heap array's order.  In the cases that are not
+//    provably immaterial the layer's search starts again with the reference's heaps restated in LDS (lds_push_parallel /
+//    lds_pop_parallel, kernels_graph.h), so ties resolve as in the reference.  (On near-isotropic 384-d rows ~12 % of
+//    the searches meet equal fp32 distances somewhere inside the heaps; ~1 % have to start again.)
 //
 //  * prune_neighbors_with_new_node recomputes the distances from the neighbour to its (<= M + 1) list members.
 //    Those are the same pure function: the distance of every stored edge is kept beside the adjacency row
@@ -28,11 +33,12 @@
 //    and d(base, new) is the new node's own search result — (a-b)^2 == (b-a)^2 bit for bit — so the prune is a stable
 //    rank of numbers already on hand and scores nothing.
 //
-//  * Several inserts are speculated at once (hnsw_insert_search_kernel: one workgroup per insert, all against the
-//    same frozen graph) and committed in order by ONE workgroup (hnsw_insert_commit_kernel).  A speculated search is
-//    used only if none of the adjacency rows it expanded was changed by an earlier insert of the same batch (each row
-//    carries the tag of the batch that last changed it) and the entry point is the same; otherwise the commit kernel
-//    searches again on the spot, or stops so that the rest of the batch is speculated again.
+//  * Several inserts are speculated at once (hnsw_insert_search_kernel: one workgroup per (insert, layer), all against
+//    the same frozen graph) and committed in order by ONE workgroup (hnsw_insert_commit_kernel).  A speculated search
+//    is adopted when it is provably the search the reference would run on the graph as it stands by then
+//    (validate_speculation: the rows it expanded are unchanged, or every node an earlier insert of the batch added to
+//    or dropped from them leaves its pops, its expansions and its result as they were); otherwise the commit kernel
+//    stops and the rest of the batch is speculated again.
 #pragma once
 #include "kernels_graph_fast.h"
 
@@ -60,7 +66,7 @@ constexpr uint32_t kLogCap = 2048;               // expanded rows remembered per
 constexpr uint32_t kLogWords = 5 * kLogCap;          // row codes | bounds W | popped distances P | first-seen masks (lo, hi)
 constexpr uint32_t kChgCap = 8192;               // row changes one commit launch remembers: (row code, node added, node dropped,
                                                  // its position in the row as the batch found it | 64 if unknown)
-constexpr uint32_t kChkCap = 1024;               // distances one validation may need
+constexpr uint32_t kChkCap = 512;                // distances one validation may need
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kTileRows = 16;               // rows of a wave's product tile
 
@@ -418,9 +424,9 @@ __device__ __forceinline__ void greedy_layer(const BuildView& g, BuildCtx& c, co
 
 // ---------------------------------------------------------------------------------------------
 // `nearest` as a SET across kNearRegs registers of wave 0: slot s lives in register s / 64, lane s % 64, slots fill in
-// admission order and an admission into the full set overwrites the slot of the maximum.  With distinct distances
-// (checked at every admission) a priority queue is a function of its contents, so the set with a running maximum
-// (`worst`) and a minimum-of-the-unexpanded reduction (the pop of `candidates`) behaves as the reference's two heaps.
+// admission order and an admission into the full set overwrites the slot of the maximum.  While no two equal keys meet
+// at the top of a heap a priority queue is a function of its contents, so the set with a running maximum (`worst`) and
+// a minimum-of-the-unexpanded reduction (the pop of `candidates`) behaves as the reference's two heaps.
 // Distances are kept as their bit patterns: for values >= +0 unsigned order is float order.  A free slot holds
 // (0xFFFFFFFF, +inf): "expanded" for the minimum search, equal to no finite distance.
 // ---------------------------------------------------------------------------------------------
@@ -453,7 +459,7 @@ __device__ __forceinline__ void near_reg_max(const NearSet& h, int r, uint32_t e
 // ---------------------------------------------------------------------------------------------
 // search_layer(query, start, ef, layer) (:469-554), whole workgroup.  Result: the first min(64, |nearest|) members in
 // ascending order -> res[layer] (count, nodes, distances).
-// EXACT = false: `nearest` as a register set; returns false (nothing written) when two members met with equal distances.
+// EXACT = false: `nearest` as a register set; returns false when equal distances met where the heap layout could matter.
 // EXACT = true : the reference's heaps restated in LDS; returns false when `candidates` outgrew its LDS slots.
 //
 // Rounds.  A table of kSlots scored adjacency lists lives in LDS (slot -> node in a register of wave 0).  Wave 0
@@ -930,30 +936,66 @@ __device__ __forceinline__ void insert_links(const BuildView& g, BuildCtx& c, ui
       }
       if (lane == 0) adj[mine] = take;
     }
-    for (uint32_t t = c.wave; t < take; t += kBuildWaves) {
-      const uint32_t nbv = r[2 + t];
-      const float dn = __uint_as_float(r[2 + 64 + t]);
-      if (lc > 0 && g.level[nbv] < lc) continue;  // :323 (a start node taken from a lower layer)
-      const size_t at = lc == 0 ? (size_t)nbv * g.stride0 : (size_t)(g.ubase[nbv] + lc - 1) * g.strideU;
-      const uint32_t k = __builtin_amdgcn_readfirstlane(adj[at]);
+    // Back-links: neighbour t belongs to wave t % 8 (distinct neighbours, distinct rows: no order between them).  A wave
+    // first REQUESTS everything its (up to 8) neighbours need — level / row index, count, row, edge distances, stamp —
+    // and only then works through them: one memory latency per layer instead of three per neighbour.
+    constexpr int kPer = (63 + kBuildWaves - 1) / kBuildWaves;
+    uint32_t p_nb[kPer], p_row[kPer], p_k[kPer], p_en[kPer], p_st[kPer];
+    float p_dn[kPer], p_ed[kPer];
+    bool p_on[kPer];
+    uint32_t* stamps = lc == 0 ? g.stamp0 : g.stampU;
+#pragma unroll
+    for (int s = 0; s < kPer; ++s) {
+      const uint32_t t = (uint32_t)c.wave + (uint32_t)s * kBuildWaves;
+      p_on[s] = t < take;
+      p_nb[s] = p_on[s] ? r[2 + t] : 0u;
+      p_dn[s] = p_on[s] ? __uint_as_float(r[2 + 64 + t]) : 0.0f;
+      p_row[s] = p_nb[s];
+    }
+    if (lc > 0) {
+#pragma unroll
+      for (int s = 0; s < kPer; ++s)
+        if (p_on[s]) {
+          p_on[s] = g.level[p_nb[s]] >= lc;  // :323 (a start node taken from a lower layer)
+          p_row[s] = g.ubase[p_nb[s]] + lc - 1;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < kPer; ++s) {
+      p_k[s] = p_en[s] = p_st[s] = 0;
+      p_ed[s] = 0.0f;
+      if (p_on[s]) {
+        const size_t at = (size_t)p_row[s] * stride;
+        p_k[s] = adj[at];
+        if ((uint32_t)lane + 1 < stride) {
+          p_en[s] = adj[at + 1 + lane];
+          p_ed[s] = adjd[at + 1 + lane];
+        }
+        p_st[s] = stamps[p_row[s]];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < kPer; ++s) {
+      if (!p_on[s]) continue;
+      const uint32_t nbv = p_nb[s], row = p_row[s];
+      const float dn = p_dn[s];
+      const size_t at = (size_t)row * stride;
+      const uint32_t code = lc == 0 ? nbv : (0x80000000u | row);
+      const uint32_t k = __builtin_amdgcn_readfirstlane(p_k[s]);
       if (k < m && k + 1 < stride) {  // room: append (:324)
         if (lane == 0) {
           adj[at + 1 + k] = node;
           adjd[at + 1 + k] = dn;
           adj[at] = k + 1;
-          (lc == 0 ? g.stamp0[nbv] : g.stampU[g.ubase[nbv] + lc - 1]) = tag;
-          record(lc == 0 ? nbv : (0x80000000u | (g.ubase[nbv] + lc - 1)), node, kNone, 64u);
+          stamps[row] = tag;
+          record(code, node, kNone, 64u);
         }
         continue;
       }
       // prune_neighbors_with_new_node (:588-624): the list + the new node, stable sort by distance, keep m
       const uint32_t tot = k + 1;  // <= 64: the row stride bounds k
-      uint32_t e_n = node;
-      float e_d = dn;
-      if ((uint32_t)lane < k) {
-        e_n = adj[at + 1 + lane];
-        e_d = adjd[at + 1 + lane];
-      }
+      const uint32_t e_n = (uint32_t)lane < k ? p_en[s] : node;
+      const float e_d = (uint32_t)lane < k ? p_ed[s] : dn;
       uint32_t rank = 0;
       for (uint32_t j = 0; j < tot; ++j) {
         const float dj = rlane_f(e_d, j);
@@ -968,14 +1010,12 @@ __device__ __forceinline__ void insert_links(const BuildView& g, BuildCtx& c, ui
         }
         const uint32_t added = __builtin_amdgcn_readlane(rank, k) < m ? node : kNone;  // lane k holds the new node
         uint64_t out = __ballot((uint32_t)lane < k && rank >= m);
-        uint32_t* stamp = lc == 0 ? &g.stamp0[nbv] : &g.stampU[g.ubase[nbv] + lc - 1];
         // the row as this batch's speculations read it: positions are still theirs if nobody of the batch rewrote it
-        const bool untouched = __builtin_amdgcn_readfirstlane(*stamp) != tag;
+        const bool untouched = __builtin_amdgcn_readfirstlane(p_st[s]) != tag;
         if (lane == 0) {
           adj[at] = min(tot, m);
-          *stamp = tag;
+          stamps[row] = tag;
         }
-        const uint32_t code = lc == 0 ? nbv : (0x80000000u | (g.ubase[nbv] + lc - 1));
         bool first = true;
         do {  // (members only moved: nothing to remember — a search that depends on list order takes the stamp alone)
           uint32_t dropped = kNone, pos = 64;
@@ -1013,6 +1053,14 @@ __device__ __forceinline__ void insert_links(const BuildView& g, BuildCtx& c, ui
 // hop (ef = 1) is the case t_out = k: the hop ended on distance W_k and x is farther.  Anything else is a conflict:
 // x within the final set, x nearer than a later pop, ANY change to an expanded row when the search met equal distances
 // (list order then matters: the speculation says so in its header), and any change at all in `strict` mode.
+//
+// Two second looks (layer 0, x alone inside the set meanwhile), both for an x that IS popped before it can leave:
+//  * dropped x that the logged run went on to expand: harmless if the search, no longer meeting x at e_k, meets it in
+//    the row of a later expansion that comes before x's own — x then enters there, nothing was popped differently;
+//  * added x that the new run pops (a later logged pop is farther): harmless if that expansion admits nobody — every
+//    node of x's row is one the search has met by then (rows of the expansions so far, marked in the visited bitmap),
+//    is soft-deleted, or is not nearer than the maximum of the moment — and no later pop is the set's maximum (the
+//    element x displaces must not be the one the logged run expands) until W drops below d(q, x).
 //
 // Returns 0 (adopt) or the cause.  Uses the searches' scratch (dist / nbr / slist / cand), idle between two inserts.
 // ---------------------------------------------------------------------------------------------
@@ -1098,32 +1146,161 @@ __device__ __forceinline__ uint32_t validate_speculation(const BuildView& g, Bui
   }
   score_lists<NB, FULL>(g, c, q2, nchk);  // dist[i] overwrites the touched-row list, which is no longer needed
   __syncthreads();
+  // ---- stage 1, one thread per check: the rule above.  Outcome in k_res[i]: state << 22 | a << 11 | b with
+  //      0 x never entered the set, 1 x was inside over the expansions (k, b], 2 second look needed (below), 3 conflict
+  uint32_t* k_res = (uint32_t*)c.cand + kChkCap;
   for (uint32_t i = threadIdx.x; i < nchk; i += kBuildThreads) {
     const float dx = c.dist[i];
     const uint32_t ref = k_ref[i] & 0x7FFFFFFFu;
+    const bool dropped = (k_ref[i] >> 31) != 0;
     const uint32_t l = ref / kLogCap, k = ref % kLogCap;
     const uint32_t* el = elog + (size_t)l * kLogWords;
     const uint32_t nlog = sp[24 + l], seg0 = sp[56 + l];
-    uint32_t why = 6;  // the log ends with x still inside the set (or the set never filled)
+    uint32_t state = 3, a = 0, b = 0, why = 6;  // 6: the log ends with x still inside the set (or the set never filled)
     if (k < seg0) {
-      why = __uint_as_float(el[kLogCap + k]) < dx ? 0u : 5u;
+      if (__uint_as_float(el[kLogCap + k]) < dx) state = 0;
+      else why = 5;
     } else {
-      for (uint32_t t = k; t < nlog; ++t) {
+      uint32_t t = k;
+      for (; t < nlog; ++t) {
         const uint32_t pt = el[2 * kLogCap + t];
         // (a pop that shared its distance with another: the pair's order is immaterial only while neither expansion
         // admits anything nearer than the pair — x, met at such an expansion, has to be farther than that pop as well)
-        if ((t > k || (pt >> 31)) && !(__uint_as_float(pt & 0x7FFFFFFFu) < dx)) {
-          why = 5;  // a later pop is not nearer than x
-          break;
-        }
+        if ((t > k || (pt >> 31)) && !(__uint_as_float(pt & 0x7FFFFFFFu) < dx)) break;  // a pop not nearer than x
         if (__uint_as_float(el[kLogCap + t]) < dx) {
-          why = 0;
+          state = t == k ? 0u : 1u;
+          b = t;
           break;
         }
       }
+      if (state == 3 && t < nlog && t > k && l == 0) {
+        // x is inside the set when a candidate farther than x is popped: x itself is popped first.
+        const uint32_t pt = el[2 * kLogCap + t];
+        why = 5;
+        if (dropped) {
+          // the logged run popped x (= the row logged at t) — harmless if the search, no longer meeting x at k, meets it
+          // in another row before that pop (second look: rows k+1 .. t-1)
+          if (pt == __float_as_uint(dx) && el[t] == c.nbr[i]) {
+            state = 2;
+            a = t;
+            b = t;
+          }
+        } else if ((pt >> 31) == 0 && __uint_as_float(pt) > dx) {
+          // the run with x pops x before the candidate of t.  If that expansion admits nobody (second look) the run goes on
+          // as logged, x inside the set until W drops below it — provided no later pop is the set's (displaced) maximum
+          uint32_t u = t;
+          bool ok = true;
+          for (; u < nlog; ++u) {
+            const uint32_t pu = el[2 * kLogCap + u];
+            if ((pu >> 31) || !(pu < el[kLogCap + u - 1])) {
+              ok = false;
+              atomicAdd(&g.state->why[17], 1u);
+              break;
+            }
+            if (__uint_as_float(el[kLogCap + u]) < dx) break;
+          }
+          if (ok && u < nlog) {
+            state = 2;
+            a = t;
+            b = u;
+          } else if (ok) {
+            why = 6;
+          }
+        }
+      } else if (state == 3 && t < nlog) {
+        why = 5;
+      }
     }
-    if (why && (k_ref[i] >> 31)) why = 9;
-    if (why) atomicMax(&c.misc[MS_CONFLICT], why);
+    if (state == 3) atomicMax(&c.misc[MS_CONFLICT], dropped ? 9u : why);
+    k_res[i] = state << 22 | a << 11 | b;
+  }
+  __syncthreads();
+  if (c.misc[MS_CONFLICT]) return c.misc[MS_CONFLICT];
+  // ---- stage 2: the checks that asked for a second look (few).  Each must be alone in the set while it is there: the
+  //      arguments above are for one displaced maximum at a time.
+  uint32_t n2 = 0;
+  for (uint32_t i = 0; i < nchk && n2 <= 4; ++i) n2 += (k_res[i] >> 22) == 2 ? 1u : 0u;
+  if (n2 == 0) return 0;
+  if (n2 > 4) return 4;
+  const uint32_t* el = elog;  // layer 0
+  const uint32_t seg0 = sp[56];
+  for (uint32_t i = 0; i < nchk; ++i) {
+    if ((k_res[i] >> 22) != 2) continue;
+    const uint32_t k = (k_ref[i] & 0x7FFFFFFFu) % kLogCap, ta = (k_res[i] >> 11) & 2047u, tb = k_res[i] & 2047u;
+    const bool dropped = (k_ref[i] >> 31) != 0;
+    const uint32_t x = c.nbr[i];
+    __syncthreads();
+    if (threadIdx.x == 0) c.misc[MS_DONE] = 0;
+    __syncthreads();
+    // (a) nobody else inside the set during (k, tb]
+    for (uint32_t o = threadIdx.x; o < nchk; o += kBuildThreads) {
+      const uint32_t so = k_res[o] >> 22;
+      if (o == i || so == 0 || (k_ref[o] & 0x7FFFFFFFu) / kLogCap != 0) continue;
+      const uint32_t ko = (k_ref[o] & 0x7FFFFFFFu) % kLogCap, bo = k_res[o] & 2047u;
+      if (ko < seg0) continue;
+      if (ko < tb && k < bo) {
+        c.misc[MS_CONFLICT] = dropped ? 9u : 5u;
+        atomicAdd(&g.state->why[15], 1u);
+      }
+    }
+    if (dropped) {
+      // (b) x in the row of an expansion after k and before its own: met there instead
+      for (uint32_t t = k + 1 + (uint32_t)c.wave; t < ta; t += kBuildWaves) {
+        const uint32_t* row = g.adj0 + (size_t)el[t] * g.stride0;
+        const uint32_t cnt = __builtin_amdgcn_readfirstlane(row[0]);
+        const bool hit = (uint32_t)c.lane < cnt && row[1 + c.lane] == x;
+        if (__ballot(hit) && c.lane == 0) c.misc[MS_DONE] = 1;
+      }
+      __syncthreads();
+      if (c.misc[MS_DONE] == 0 && threadIdx.x == 0) c.misc[MS_CONFLICT] = 9;
+    } else {
+      // (b) everything the search has met before it pops x: the rows of the expansions seg0 .. ta-1 and their nodes
+      clear_bitmap(g, c);
+      __syncthreads();
+      for (uint32_t t = seg0 + (uint32_t)c.wave; t < ta; t += kBuildWaves) {
+        const uint32_t e = el[t];
+        const uint32_t* row = g.adj0 + (size_t)e * g.stride0;
+        const uint32_t cnt = __builtin_amdgcn_readfirstlane(row[0]);
+        if ((uint32_t)c.lane < cnt) {
+          const uint32_t y = row[1 + c.lane];
+          atomicOr(&c.bitmap[y >> 5], 1u << (y & 31));
+        }
+        if (c.lane == 0) atomicOr(&c.bitmap[e >> 5], 1u << (e & 31));
+      }
+      __syncthreads();
+      // (c) x's own row: whoever is new to the search and alive must be turned away (not nearer than the maximum then)
+      if (c.wave == 0) {
+        const uint32_t* row = g.adj0 + (size_t)x * g.stride0;
+        const uint32_t cnt = __builtin_amdgcn_readfirstlane(row[0]);
+        bool fresh = false;
+        uint32_t y = 0;
+        if ((uint32_t)c.lane < cnt) {
+          y = row[1 + c.lane];
+          fresh = ((c.bitmap[y >> 5] >> (y & 31)) & 1u) == 0 && !(g.any_deleted && g.deleted[y]);
+        }
+        const uint64_t fm = __ballot(fresh);
+        if (fresh) {
+          const uint32_t at = kChkCap + (uint32_t)__popcll(fm & ((1ull << c.lane) - 1));  // above the checks' own entries
+          c.nbr[at] = y;
+          c.slist[(uint32_t)__popcll(fm & ((1ull << c.lane) - 1))] = (uint16_t)at;
+        }
+        if (c.lane == 0) c.misc[MS_NSCORE] = (uint32_t)__popcll(fm);
+      }
+      __syncthreads();
+      const uint32_t nf = c.misc[MS_NSCORE];
+      // (slist is rewritten: the checks' entries are i -> i, restored below)
+      score_lists<NB, FULL>(g, c, q2, nf);
+      __syncthreads();
+      const float w = __uint_as_float(el[kLogCap + ta - 1]);
+      if (threadIdx.x < nf && c.dist[kChkCap + threadIdx.x] < w) {
+        c.misc[MS_CONFLICT] = 5;
+        atomicAdd(&g.state->why[16], 1u);
+      }
+      __syncthreads();
+      for (uint32_t o = threadIdx.x; o < min(nchk, 64u); o += kBuildThreads) c.slist[o] = (uint16_t)o;
+    }
+    __syncthreads();
+    if (c.misc[MS_CONFLICT]) break;
   }
   __syncthreads();
   const uint32_t why = c.misc[MS_CONFLICT];
