@@ -562,9 +562,15 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
   uint32_t done = 0;
   uint32_t exact_positions = 4;  // speculated searches of a batch that may start again with the restated heaps on a tie
   uint32_t ties_seen = 0;
+  static const int env_xf = getenv("FVDB_BUILD_EXACT_FIRST") ? atoi(getenv("FVDB_BUILD_EXACT_FIRST")) : 1;    // A/B
+  // where ties are the rule (duplicate vectors) the register-set attempt is wasted work: the next `exact_left` rounds of
+  // this loop go straight to the restated heaps, then the question is asked again
+  uint32_t exact_left = 0, commit_ties_seen = 0;
   while (done < n) {
     const bool speculate = mode == 2 || (mode == 0 && (uint64_t)first + done >= seq_below && n - done >= 8);
     uint32_t launches = 0;
+    v.exact_first = exact_left > 0 ? 1u : 0u;
+    if (exact_left) exact_left -= 1;
     if (!speculate) {
       uint32_t chunk = std::min<uint32_t>(n - done, 2048);  // bounds one launch to a fraction of a second
       if (mode == 0 && (uint64_t)first + done < seq_below) chunk = std::min<uint32_t>(chunk, seq_below - (first + done));
@@ -602,9 +608,12 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
     }
     if (speculate && launches >= 2) {  // where ties are the rule (duplicate vectors) every speculation takes the exact search
       const uint32_t searched = (launches / 2) * K, tied = st.spec_ties - ties_seen;
-      exact_positions = 4 * tied > searched ? Kmax : 4;
+      if (!v.exact_first) exact_positions = 4 * tied > searched ? Kmax : 4;
+      if (env_xf && !v.exact_first && 2 * tied > searched) exact_left = 8;
       ties_seen = st.spec_ties;
     }
+    if (!speculate && env_xf && !v.exact_first && 2 * (st.ties - commit_ties_seen) > st.cursor - before) exact_left = 8;
+    commit_ties_seen = st.ties;
     if (st.cursor == done && st.status == 0) FAIL(ctx, FVDB_E_HIP, "device insert made no progress");
     done = st.cursor;
     if (st.status) break;

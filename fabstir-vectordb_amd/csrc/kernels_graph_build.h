@@ -100,6 +100,7 @@ struct BuildView {
   uint32_t M, M0, ef;
   uint32_t bitmap_words;  // visited bitmap (LDS) words: covers every node index of the graph
   uint32_t cand_cap;      // restated `candidates` heap slots in LDS
+  uint32_t exact_first;   // 1: skip the register-set attempt (data on which nearly every search has to start again)
   BuildState* state;
   unsigned long long* dbg;  // diagnostic builds (-DFVDB_BUILD_STAMPS): phase times in 10 ns ticks, see fvdb_graph.cpp
 };
@@ -844,7 +845,7 @@ template <int NB, bool FULL>
 __device__ __forceinline__ bool ef_search(const BuildView& g, BuildCtx& c, const float2 (&q2)[NB], uint32_t layer, uint32_t start,
                                           float start_d, uint32_t* elog, uint32_t* stat, bool exact_on_tie) {
   const uint32_t log0 = c.misc[MS_NLOG];
-  if (g.ef <= (uint32_t)kNearRegs * 64u) {
+  if (g.ef <= (uint32_t)kNearRegs * 64u && !g.exact_first) {
     if (ef_search_layer<NB, FULL, false>(g, c, q2, layer, start, start_d, elog, stat)) return true;
     if (threadIdx.x == 0 && stat) stat[3] += 1;
     if (!exact_on_tie) return false;  // a speculation far down the batch: not worth twice the time of the others

@@ -22,10 +22,7 @@ def summ(rs):
     if rs:
         out["wall_ms"] = round((int(rs[-1]["End_Timestamp"]) - int(rs[0]["Start_Timestamp"])) / 1e6, 2)
     return out
-# the insert_path sample is the last call: its launches come after the last long gap (the bench's timed region)
-gaps = [(int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"]), i) for i in range(len(rows) - 1)]
-cut = max(gaps)[1] + 1
-res = {"build_300k": summ(rows[:cut]), "insert_sample": summ(rows[cut:])}
+res = {"what": "every launch of the device-resident insert in one bench.py run: the 300K-node sequential build of the headline's graph (no insert sample: --no-cpu-baseline)", "all": summ(rows)}
 open("$O/insert_kernels_summary.json", "w").write(json.dumps(res, indent=1))
 print(json.dumps(res, indent=1))
 PY

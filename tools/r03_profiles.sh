@@ -55,3 +55,7 @@ echo "== isotropic cliff"; python3 tools/iso_cliff.py > $O/isotropic_filter.log 
 echo "== sequential build: C1 shapes and 300K"
 python3 tools/build_bench.py --n 10000 --d 384 --mode 0 --check > $O/build_c1_mixture.log 2>&1; tail -n 3 $O/build_c1_mixture.log | cut -c1-300
 python3 tools/build_bench.py --n 10000 --d 384 --mode 0 --gen refbench --check > $O/build_c1_refbench.log 2>&1; tail -n 3 $O/build_c1_refbench.log | cut -c1-300
+FVDB_BUILD_DEBUG=1 python3 tools/build_bench.py --n 300000 --d 384 --mode 0 --tail 2048 --tail-mode 0 2>&1 | grep -v "1 linked" > $O/build_300k_mixture.log; tail -n 3 $O/build_300k_mixture.log | cut -c1-300
+echo "== insert kernels, traced"; bash tools/insert_trace.sh; cp gpurun_out/ins/insert_kernels_summary.json $O/insert_kernels_summary.json
+cat $O/build_c1_mixture.log $O/build_c1_refbench.log $O/build_300k_mixture.log > $O/side_workloads_builds.log
+du -sh gpurun_out
