@@ -655,11 +655,26 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
               uint32_t holders = 0;
 #pragma unroll
               for (int r = 0; r < kNearRegs; ++r) holders += rm[r] == worst ? rc[r] : 0u;
-              if (holders > 1) amb = worst;  // two members share the largest distance: which one leaves is the layout's business
-              near_write(h, wr * 64u + rl[wr], ni, di);
+              uint32_t er = wr, el_ = rl[wr];  // the slot that is given up
+              if (holders > 1) {
+                // two members share the largest distance: which one leaves is the layout's business.  An EXPANDED one is
+                // sent away if there is one: whichever the reference keeps, a survivor that can still be popped is then
+                // in this set too, and its pop (if it comes to that) is seen and ends the attempt.
+                amb = worst;
+#pragma unroll
+                for (int r = kNearRegs - 1; r >= 0; --r) {
+                  const bool in = (uint32_t)(r * 64 + lane) < ef;
+                  const uint64_t ex = __ballot(in && h.d[r] == worst && (h.n[r] >> 31) != 0);
+                  if (ex) {
+                    er = (uint32_t)r;
+                    el_ = (uint32_t)__builtin_ctzll(ex);
+                  }
+                }
+              }
+              near_write(h, er * 64u + el_, ni, di);
 #pragma unroll
               for (int r = 0; r < kNearRegs; ++r)
-                if (wr == (uint32_t)r) near_reg_max(h, r, ef, lane, rm[r], rl[r], rc[r]);
+                if (er == (uint32_t)r) near_reg_max(h, r, ef, lane, rm[r], rl[r], rc[r]);
               pick_worst();
             }
           }
@@ -1068,7 +1083,8 @@ __device__ __forceinline__ void insert_links(const BuildView& g, BuildCtx& c, ui
 template <int NB, bool FULL>
 __device__ __forceinline__ uint32_t validate_speculation(const BuildView& g, BuildCtx& c, uint32_t node, uint32_t level, uint32_t tag,
                                                          const uint32_t* __restrict__ sp, const uint32_t* __restrict__ elog, const uint32_t* chg,
-                                                         bool strict) {
+                                                             uint32_t strict /* A/B and bisecting: 1 any change is a conflict, 2 no second
+                                                         looks, 4 no first-seen skip, 8 x must be turned away at once */) {
   uint32_t* t_code = (uint32_t*)c.dist;            // touched rows of the log: code, position (layer * kLogCap + entry)
   uint32_t* t_ref = (uint32_t*)c.dist + kChkCap;
   uint32_t* k_ref = (uint32_t*)c.cand;             // checks: node in nbr[i], log position here (cand_cap >= 512 items)
@@ -1078,7 +1094,7 @@ __device__ __forceinline__ uint32_t validate_speculation(const BuildView& g, Bui
     c.misc[MS_NCHK] = 0;
   }
   __syncthreads();
-  const bool coarse = strict || chg == nullptr || c.misc[MS_CHGOVER] != 0;
+  const bool coarse = (strict & 1u) || chg == nullptr || c.misc[MS_CHGOVER] != 0;
   for (uint32_t l = 0; l <= level; ++l) {
     const uint32_t nlog = sp[24 + l];
     const bool order = sp[40 + l] != 0;
@@ -1118,7 +1134,7 @@ __device__ __forceinline__ uint32_t validate_speculation(const BuildView& g, Bui
           // there: the row without it reads the same.  Known when the change was the batch's first to the row.
           const uint32_t pos = chg[4 * r + 3], ref = t_ref[t];
           const uint32_t l = ref / kLogCap, k = ref % kLogCap;
-          if (pos < 64 && k >= sp[56 + l]) {
+          if (pos < 64 && k >= sp[56 + l] && !(strict & 4u)) {
             const uint32_t* el = elog + (size_t)l * kLogWords;
             const uint32_t w = el[(pos < 32 ? 3 : 4) * kLogCap + k];
             if (((w >> (pos & 31)) & 1u) == 0) continue;
@@ -1173,8 +1189,9 @@ __device__ __forceinline__ uint32_t validate_speculation(const BuildView& g, Bui
           b = t;
           break;
         }
+        if (strict & 8u) break;
       }
-      if (state == 3 && t < nlog && t > k && l == 0) {
+      if (state == 3 && t < nlog && t > k && l == 0 && !(strict & 2u)) {
         // x is inside the set when a candidate farther than x is popped: x itself is popped first.
         const uint32_t pt = el[2 * kLogCap + t];
         why = 5;
@@ -1404,7 +1421,7 @@ __global__ __launch_bounds__(kBuildThreads, 1) void hnsw_insert_commit_kernel(co
       for (uint32_t l = 0; l <= level; ++l) usable = usable && sp[8 + l] == tag;
       uint32_t why = sp[1] == node && sp[2] == st.entry ? 2u : 1u;
       if (usable) {
-        why = validate_speculation<NB, FULL>(g, c, node, level, tag, sp, elogs + (size_t)b * kBuildLayers * kLogWords, chg, strict != 0);
+        why = validate_speculation<NB, FULL>(g, c, node, level, tag, sp, elogs + (size_t)b * kBuildLayers * kLogWords, chg, strict);
         have = why == 0;
         n_chk += c.misc[MS_NCHK];
         n_touch += c.misc[MS_NT];

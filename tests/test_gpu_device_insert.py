@@ -2,6 +2,9 @@
 src/hnsw/core.rs:226-378): the graph must be the CPU oracle's node for node whichever way the inserts run — one at a
 time on the device, speculated in batches and committed in order, or by the host algorithm with per-hop GPU scoring —
 and the incremental device mirror must move O(M x levels) bytes per insert, never the whole graph."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -241,3 +244,19 @@ def test_interleaved_inserts_and_searches_move_rows_not_the_graph(fv, ctx):
         assert per_insert <= (8 if mode else 4 * (2 + 64 + 2) * (17 + 4 * 9)) + 64
     assert gh.device_fallbacks() == 0
     same_graph(gh, oh)
+
+
+def test_randomised_shapes_build_the_oracles_graph(fv, ctx):
+    # tools/insert_fuzz.py: dimension, degrees, ef_construction, cluster structure, exact duplicates, vectors on a coarse
+    # grid (equal distances between different vectors), soft deletes between batches, forced / chosen speculation — every
+    # case list by list against the oracle.  (This sweep is what found the tied-maximum case that must send an EXPANDED
+    # member away; longer sweeps: python tools/insert_fuzz.py --cases 60 --seed N.)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import insert_fuzz
+    rng = np.random.default_rng(1)
+    failed = []
+    for c in range(56):  # the generator is advanced through every case; the listed ones are built (55: the tied maximum)
+        only = c if c in (3, 11, 17, 23, 31, 38, 42, 45, 50, 55) else -2
+        if insert_fuzz.one_case(fv, orc, ctx, rng, c, only):
+            failed.append(c)
+    assert not failed, failed
