@@ -717,8 +717,9 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
             ns += 1;
           }
         } else {
-          // all unexpanded members with distance <= t, t = the largest threshold (bisection on the bit pattern) that
-          // names at most kSpec of them; the minimum is always among them
+          // all unexpanded members with distance <= t, t = a threshold (bisection on the bit pattern) that names at most
+          // kSpec of them — and at least half as many, then it is good enough: which lists are brought on chip ahead of
+          // their pop changes nothing but the number of rounds; the minimum is always among them
           uint32_t key[kNearRegs], m = 0xFFFFFFFFu;
 #pragma unroll
           for (int r = 0; r < kNearRegs; ++r) {
@@ -739,7 +740,7 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
               const uint32_t cn = count_le(mid);
               if (cn <= (uint32_t)kSpec) lo = mid;
               else hi = mid;
-              if (cn == (uint32_t)kSpec) break;
+              if (cn <= (uint32_t)kSpec && 2 * cn >= (uint32_t)kSpec) break;
             }
             t = lo;
           }
