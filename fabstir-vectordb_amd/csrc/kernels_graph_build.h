@@ -229,17 +229,12 @@ __device__ __forceinline__ float wave_min_f(float v) {
   return rlane_f(v, 63);
 }
 
-// lane `l` of `old` <- `value` (both wave-uniform).  The wait states a VALU-written SGPR needs before it selects a lane
-// are spelled out: hipcc does not insert them around an asm statement.
+// lane `l` of `old` <- `value` (both wave-uniform): one compare and one select.  (v_writelane_b32 through inline asm cost
+// more: the lane select has to travel in M0, the wait states around it are spelled out by hand, and the tied operand made
+// the compiler copy the registers of the set around every call — ~100 instructions per admission in the replay loop.)
 __device__ __forceinline__ uint32_t writelane_u(uint32_t value, uint32_t l, uint32_t old) {
-  const uint32_t sv = __builtin_amdgcn_readfirstlane(value), sl = __builtin_amdgcn_readfirstlane(l);
-  // gfx9 allows one SGPR operand per VALU instruction: the lane select travels in M0, whose value (the compiler's) is
-  // put back afterwards
-  uint32_t keep;
-  asm volatile("s_nop 3\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1\n\ts_nop 1"
-               : "+v"(old), "=&s"(keep)
-               : "s"(sv), "s"(sl));
-  return old;
+  const uint32_t me = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  return me == l ? value : old;
 }
 
 // the same on unsigned values (zero fill: max's identity; min = ~max(~v))
@@ -438,13 +433,14 @@ struct NearSet {
 
 // write (node, distance bits) into slot `at` (all three wave-uniform)
 __device__ __forceinline__ void near_write(NearSet& h, uint32_t at, uint32_t node, uint32_t dbits) {
-  const uint32_t l = at & 63;
+  const uint32_t me = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const bool mine = me == (at & 63);
 #pragma unroll
-  for (int r = 0; r < kNearRegs; ++r)
-    if ((at >> 6) == (uint32_t)r) {
-      h.n[r] = writelane_u(node, l, h.n[r]);
-      h.d[r] = writelane_u(dbits, l, h.d[r]);
-    }
+  for (int r = 0; r < kNearRegs; ++r) {  // branch-free: the register is picked by a scalar condition folded into the lane mask
+    const bool hit = mine && (at >> 6) == (uint32_t)r;
+    h.n[r] = hit ? node : h.n[r];
+    h.d[r] = hit ? dbits : h.d[r];
+  }
 }
 
 // maximum of register r over the slots below ef, the lane that holds it, and how many slots hold it
@@ -595,8 +591,10 @@ __device__ __forceinline__ bool ef_search_layer(const BuildView& g, BuildCtx& c,
           (void)lds_pop_parallel(c.cand, nC, lane);
         } else {
 #pragma unroll
-          for (int r = 0; r < kNearRegs; ++r)
-            if ((slot >> 6) == (uint32_t)r) h.n[r] = writelane_u(node | 0x80000000u, slot & 63, h.n[r]);
+          for (int r = 0; r < kNearRegs; ++r) {
+            const bool hit = (uint32_t)lane == (slot & 63) && (slot >> 6) == (uint32_t)r;
+            h.n[r] = hit ? (node | 0x80000000u) : h.n[r];
+          }
         }
         consumed += 1;
         const uint32_t cnt = c.misc[MS_CNT + p];
