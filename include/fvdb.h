@@ -362,8 +362,12 @@ int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const
  *   current node count (node index = store row).
  * insert_linked: links the appended, not yet linked nodes [first, first + n) in order.  mode 0 = choose,
  *   1 = one insert at a time, 2 = speculate a batch of searches against the frozen graph and commit in order
- *   (a speculated search is adopted only if no adjacency row it expanded was changed by an earlier insert of the
- *   batch).  *n_done < n with stats->needs_host = 1: node first + *n_done needs the host path (level >= 16 or an
+ *   (a speculated search is adopted only if it is provably the search the serial algorithm would run at its turn:
+ *   the adjacency rows it expanded are unchanged, or what earlier inserts of the batch added to / dropped from them
+ *   cannot alter its pops, its expansions or its result — DESIGN.md section 6a).  The result never depends on the
+ *   mode.  Environment knobs for A/B runs only: FVDB_BUILD_MODE, FVDB_BUILD_K / FVDB_BUILD_KMAX (batch size),
+ *   FVDB_BUILD_STRICT (1 = adopt only when no expanded row changed), FVDB_BUILD_SEQ_BELOW, FVDB_BUILD_EXACT_FIRST,
+ *   FVDB_BUILD_DEBUG (per-call diagnostics on stderr).  *n_done < n with stats->needs_host = 1: node first + *n_done needs the host path (level >= 16 or an
  *   on-chip heap overflow); link it through fvdb_graph_set_lists / fvdb_graph_set_entry and call again.
  * set_lists: overwrite the lists of n_lists (node, layer) rows: offsets[n_lists + 1] into nbrs[].
  * set_entry: entry point + the number of nodes whose links are complete.
