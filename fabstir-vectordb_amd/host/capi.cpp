@@ -209,7 +209,7 @@ int fvh_hybrid_search_dev_begin(void* p, uint32_t slot, const float* q_dev, uint
 int fvh_hybrid_attach_comm(void* p, fvdb_comm* comm) { return ((HybridIndex*)p)->attach_comm(comm); }
 int fvh_hybrid_search_sharded_begin(void* p, uint32_t slot, const float* q_dev, uint32_t B, uint32_t d, uint64_t k,
                                     uint64_t ef, uint64_t nprobe, int search_recent, int search_historical,
-                                    uint64_t recent_k, uint64_t historical_k, int mode) {
+                                    uint64_t recent_k, uint64_t historical_k, int mode, double now) {
   HybridSearchConfig c;
   c.k = k;
   c.hnsw_ef = ef;
@@ -218,7 +218,7 @@ int fvh_hybrid_search_sharded_begin(void* p, uint32_t slot, const float* q_dev, 
   c.search_historical = search_historical != 0;
   c.recent_k = recent_k;
   c.historical_k = historical_k;
-  return ((HybridIndex*)p)->search_sharded_begin(slot, q_dev, B, d, c, mode);
+  return ((HybridIndex*)p)->search_sharded_begin(slot, q_dev, B, d, c, mode, now);
 }
 int fvh_hybrid_search_sharded_end(void* p, uint32_t slot, uint64_t* ids, float* dist, uint32_t* counts) {
   return ((HybridIndex*)p)->search_sharded_end(slot, ids, dist, counts);

@@ -370,11 +370,13 @@ class HybridIndex {
   // exchanges and the merge by key on the slot's stream), the graph walk of this rank's own queries beside it — and
   // search_sharded_end waits for the slot and applies the reference's hybrid merge.  mode FVDB_SHARD_WEAK: q_dev is
   // this rank's own B queries, B result rows; FVDB_SHARD_STRONG: q_dev is the global batch (same on every rank),
-  // result rows = this rank's slice [r*per, min(B,(r+1)*per)) (sharded_rows()).  Per-search auto-migration is not run
-  // in this mode.  Every rank makes the same sequence of begin/end calls.
+  // result rows = this rank's slice [r*per, min(B,(r+1)*per)) (sharded_rows()).  Every rank makes the same sequence
+  // of begin/end calls WITH THE SAME `now`: the per-search auto-migration (src/hybrid/core.rs:437-439) runs on every
+  // rank — the same due ids in the same order, assigned by the same centroids; the rank that owns a list appends the
+  // row, every rank counts it into the logical list sizes (migrate_locked).
   int attach_comm(fvdb_comm* comm);
   int search_sharded_begin(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim, const HybridSearchConfig& cfg,
-                           int mode);
+                           int mode, double now = 0.0);
   int search_sharded_end(uint32_t slot, uint64_t* ids, float* dist, uint32_t* counts) {
     return search_dev_end(slot, ids, dist, counts);
   }
@@ -449,6 +451,10 @@ class HybridIndex {
   double recent_build_s_ = 0.0;
   fvdb_comm* comm_ = nullptr;
   fvdb_sharded* sharded_ = nullptr;
+  // list placement of bulk_insert_sharded (world 0 = not sharded): owner rank and logical size of every list
+  uint32_t shard_rank_ = 0, shard_world_ = 0;
+  std::vector<uint32_t> shard_owner_;
+  std::vector<uint64_t> shard_sizes_;
   uint64_t migrate_locked(double threshold_s, double now);
   bool busy_unlocked() const {
     for (const Slot& s : slots_)

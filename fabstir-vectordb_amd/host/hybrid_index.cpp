@@ -188,6 +188,13 @@ int HybridIndex::bulk_insert_sharded(const uint64_t* ids, const float* v, uint64
         pending_min_ts_ = std::min(pending_min_ts_, ts[i]);
       }
   }
+  shard_rank_ = rank;
+  shard_world_ = world;
+  if (ivf_trained_) {
+    const uint32_t nlist = historical_->config().n_clusters;
+    shard_sizes_.assign(nlist, 0);
+    plan_list_owners(shard_sizes_, world, shard_owner_);  // (replaced below when rows go to the lists now)
+  }
   if (!hid.empty()) {
     const uint32_t nlist = historical_->config().n_clusters;
     std::vector<uint32_t> cl(hid.size());
@@ -197,6 +204,8 @@ int HybridIndex::bulk_insert_sharded(const uint64_t* ids, const float* v, uint64
     for (uint32_t c : cl) sizes[c]++;
     std::vector<uint32_t> owner;
     plan_list_owners(sizes, world, owner);
+    shard_owner_ = owner;
+    shard_sizes_ = sizes;
     if (owner_out) std::memcpy(owner_out, owner.data(), nlist * sizeof(uint32_t));
     std::vector<uint64_t> kid;
     std::vector<float> kv;
@@ -299,7 +308,30 @@ uint64_t HybridIndex::migrate_locked(double threshold_s, double now) {
     xi.push_back(id);
     xv.insert(xv.end(), vec, vec + dim);
   }
-  if (!xi.empty()) {
+  if (!xi.empty() && shard_world_ > 0 && !shard_owner_.empty()) {
+    // lists live on their owner ranks (bulk_insert_sharded): every rank runs this with the same due ids in the same
+    // order and the same centroids — the owner of a row's list appends it, every rank counts it into the logical list
+    // sizes, so list order and the selection keys' positions are what the unsharded index would have.  (An id that
+    // is already in a list of ANOTHER rank cannot be seen here; ids that are still pending were never copied.)
+    std::vector<uint32_t> cl(xi.size());
+    if (historical_->assign(xv.data(), xi.size(), dim, cl.data())) return 0;
+    std::vector<uint64_t> kid;
+    std::vector<float> kv;
+    std::vector<uint32_t> kc;
+    for (size_t i = 0; i < xi.size(); ++i) {
+      shard_sizes_[cl[i]] += 1;
+      if (shard_owner_[cl[i]] == shard_rank_) {
+        kid.push_back(xi[i]);
+        kc.push_back(cl[i]);
+        kv.insert(kv.end(), xv.begin() + i * dim, xv.begin() + (i + 1) * dim);
+      }
+    }
+    uint64_t ok = 0;
+    int err = 0;
+    if (!kid.empty() && historical_->batch_insert_assigned(kid.data(), kv.data(), kid.size(), dim, kc.data(), &ok, &err)) return 0;
+    if (fvdb_ivf_set_global_list_sizes(historical_->device(), shard_sizes_.data())) return 0;
+    migrated = xi.size();
+  } else if (!xi.empty()) {
     int err = 0;
     int rc = historical_->batch_insert(xi.data(), xv.data(), xi.size(), dim, &migrated, &err);
     if (rc) return 0;  // IVF untrained / dimension mismatch: every insert fails; ids stay pending
@@ -410,8 +442,23 @@ uint32_t HybridIndex::sharded_rows(uint32_t B, int mode) const {
 }
 
 int HybridIndex::search_sharded_begin(uint32_t slot, const float* q_dev, uint32_t B, uint32_t dim,
-                                      const HybridSearchConfig& cfg, int mode) {
+                                      const HybridSearchConfig& cfg, int mode, double now) {
   if (slot >= kSlots || !sharded_ || (mode != FVDB_SHARD_WEAK && mode != FVDB_SHARD_STRONG)) return FVDB_E_INVALID;
+  // per-search auto-migration as in search_dev_begin; `now` is the same on every rank, so every rank migrates the same
+  // rows at the same step (a due migration while batches are in flight is refused: collect first)
+  if (initialized_ && cfg.k != 0 && cfg_.auto_migrate) {
+    bool others;
+    {
+      std::lock_guard<std::mutex> lk(slot_mu_);
+      if (slots_[slot].active) return FVDB_E_INVALID;
+      others = busy_unlocked();
+    }
+    std::unique_lock<std::shared_mutex> w(rw_);
+    if (migration_due(cfg_.recent_threshold_s, now)) {
+      if (others || busy()) return FVDB_E_INVALID;
+      migrate_locked(cfg_.recent_threshold_s, now);
+    }
+  }
   std::shared_lock<std::shared_mutex> r(rw_);
   {
     std::lock_guard<std::mutex> lk(slot_mu_);

@@ -84,7 +84,7 @@ HOST_SIGNATURES = {
     "fvh_hybrid_search_dev_begin": (i32, [vp, u32, vp, u32, u32, u64, u64, u64, i32, i32, u64, u64, dbl]),
     "fvh_hybrid_search_dev_end": (i32, [vp, u32, u64p, f32p, u32p]),
     "fvh_hybrid_attach_comm": (i32, [vp, vp]),
-    "fvh_hybrid_search_sharded_begin": (i32, [vp, u32, vp, u32, u32, u64, u64, u64, i32, i32, u64, u64, i32]),
+    "fvh_hybrid_search_sharded_begin": (i32, [vp, u32, vp, u32, u32, u64, u64, u64, i32, i32, u64, u64, i32, dbl]),
     "fvh_hybrid_search_sharded_end": (i32, [vp, u32, u64p, f32p, u32p]),
     "fvh_hybrid_sharded_rows": (u32, [vp, u32, i32]),
     "fvh_plan_list_owners": (None, [u64p, u32, u32, u32p]),
@@ -635,10 +635,10 @@ class HybridIndex(_Base):
         return int(self.lib.fvh_hybrid_sharded_rows(self.h, B, mode))
 
     def search_sharded_begin(self, slot, q_dev, B, k, mode, hnsw_ef=50, ivf_n_probe=10, search_recent=True,
-                             search_historical=True, recent_k=0, historical_k=0, dim=None):
+                             search_historical=True, recent_k=0, historical_k=0, dim=None, now=0.0):
         self._check(self.lib.fvh_hybrid_search_sharded_begin(self.h, slot, q_dev, B, dim, k, hnsw_ef, ivf_n_probe,
                                                              int(search_recent), int(search_historical), recent_k,
-                                                             historical_k, mode))
+                                                             historical_k, mode, float(now)))
         self._inflight = getattr(self, "_inflight", {})
         self._inflight[slot] = (self.sharded_rows(B, mode), k)
 

@@ -216,8 +216,8 @@ def bring_up(ctx, dist, torch, transport="rccl", timeout_s=180.0, log=print, all
 
 class ShardedHybrid:
     """HybridIndex across `comm.world` ranks (see the module docstring).  Bench / scale surface: bulk placement and
-    batched search with several steps in flight; per-search auto-migration is not run in this mode (nothing ages
-    during a bench; the single-GPU HybridIndex keeps the reference's behaviour)."""
+    batched search with several steps in flight; the per-search auto-migration (src/hybrid/core.rs:437-439) runs on
+    every rank when every rank passes the same `now` (the owner of a list appends the aged row, every rank counts it)."""
 
     SLOTS = 16
 
@@ -237,14 +237,14 @@ class ShardedHybrid:
         """Result rows this rank gets for a step of B queries."""
         return self.hyb.sharded_rows(B, mode)
 
-    def search_dev_begin(self, slot, q_dev, B, k, ef, nprobe, mode=WEAK):
+    def search_dev_begin(self, slot, q_dev, B, k, ef, nprobe, mode=WEAK, now=0.0):
         """Enqueue this rank's step in `slot` (q_dev: device pointer to B x d f32 — the rank's own batch in WEAK mode,
-        the global batch in STRONG mode).  Every rank must call begin/end in the same order."""
-        self.hyb.search_sharded_begin(slot, q_dev, B, k, mode, hnsw_ef=ef, ivf_n_probe=nprobe, dim=self.d)
+        the global batch in STRONG mode).  Every rank must call begin/end in the same order, with the same `now`."""
+        self.hyb.search_sharded_begin(slot, q_dev, B, k, mode, hnsw_ef=ef, ivf_n_probe=nprobe, dim=self.d, now=now)
 
     def search_dev_end(self, slot):
         return self.hyb.search_sharded_end(slot)
 
-    def search_dev(self, q_dev, B, k, ef, nprobe, mode=WEAK):
-        self.search_dev_begin(0, q_dev, B, k, ef, nprobe, mode)
+    def search_dev(self, q_dev, B, k, ef, nprobe, mode=WEAK, now=0.0):
+        self.search_dev_begin(0, q_dev, B, k, ef, nprobe, mode, now)
         return self.search_dev_end(0)

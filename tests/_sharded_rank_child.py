@@ -100,12 +100,31 @@ def main():
     res = S.search_dev(gdev, 1, k, ef, nprobe, sh.STRONG)
     report["checks"].append(["strong_tiny", bool(res.counts.shape[0] == (1 if rank == 0 else 0) and
                                                  (rank != 0 or same(res, glob[:1])))])
+    # ten days later every recent row is due: each rank migrates the same rows at the same step (the owner of a list
+    # appends them); results and counts equal the unsharded index's on this GPU, whose migration is oracle-checked
+    plain = fv.HybridIndex(ctx, max_connections=8, max_connections_layer_0=16, ef_construction=40, n_clusters=nlist,
+                           n_probe=nprobe, hnsw_seed=19)
+    plain.set_ivf_centroids(cents)
+    plain.bulk_insert(ids, x, ts, now)
+    later = now + 10 * DAY
+
+    def same_plain(res, q_rows):
+        p = plain.search_dev(ctx.upload(q_rows), q_rows.shape[0], k, now=later, hnsw_ef=ef, ivf_n_probe=nprobe, dim=d)
+        return bool(np.array_equal(res.counts, p.counts) and np.array_equal(res.ids, p.ids) and
+                    np.array_equal(bits(res.distances), bits(p.distances)))
+
+    res = S.search_dev(own_dev[1], B, k, ef, nprobe, sh.WEAK, now=later)
+    ok = same_plain(res, own[1]) and hyb.recent_count() == 0 and hyb.historical_count() == n
+    ok = ok and any(len(set(res.ids[b, : res.counts[b]].tolist())) < res.counts[b] for b in range(B))
+    report["checks"].append(["weak_after_migration", bool(ok)])
+    res = S.search_dev(gdev, B, k, ef, nprobe, sh.STRONG, now=later)
+    report["checks"].append(["strong_after_migration", bool(same_plain(res, glob[lo:hi]))])
     # how often the matrix-core filter had to hand a query to the exact rescan on this rank (thresholds shared
     # between the ranks must not make that the normal case)
     fb = C.c_uint64(0)
     ctx.lib.fvdb_ivf_scan_fallbacks(hyb.ivf()._dev(), C.byref(fb))
     report["scan_fallbacks"] = int(fb.value)
-    report["queries_scanned"] = int(world * B * 4 + B * 2)  # weak: 4 steps of world*B; strong: B and 1
+    report["queries_scanned"] = int(world * B * 5 + B * 3)  # weak: 5 steps of world*B; strong: B, 1 and B
     report["ok"] = all(c[1] for c in report["checks"])
     json.dump(report, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
     dist.barrier()

@@ -47,7 +47,8 @@ def test_every_rank_of_the_sharded_search_matches_the_oracle(tmp_path, world):
     for r in range(world):
         rep = json.load(open(tmp_path / f"rank{r}.json"))
         assert rep["ok"], rep
-        assert [c[0] for c in rep["checks"]] == ["all_gather", "all_to_all", "weak", "weak_in_flight", "strong", "strong_tiny"]
+        assert [c[0] for c in rep["checks"]] == ["all_gather", "all_to_all", "weak", "weak_in_flight", "strong", "strong_tiny",
+                                                   "weak_after_migration", "strong_after_migration"]
         assert rep["scan_fallbacks"] * 5 <= rep["queries_scanned"], rep  # the filter decides, not the exact rescan
     owned = [json.load(open(tmp_path / f"rank{r}.json"))["lists_owned"] for r in range(world)]
     assert sum(owned) == 24 and min(owned) > 0

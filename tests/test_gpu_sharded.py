@@ -85,6 +85,16 @@ def test_sharded_hybrid_world_1_over_rccl_matches_oracle(fv, ctx):
     with pytest.raises(fv.FvdbError):
         hyb.insert_with_timestamp(10**6, x[0], now, now)
     S.search_dev_end(0)
+    # ten days later every recent row is due: the per-search auto-migration (src/hybrid/core.rs:437-439) copies them into
+    # the lists of their owner ranks; counts and the duplicate-bearing merged results equal the unsharded index's (whose
+    # migration is held against the oracle in test_hybrid_auto_migration_on_device_query_path)
+    later = now + 10 * DAY
+    for mode in (sh.WEAK, sh.STRONG):
+        r = S.search_dev(qd[1], B, k, ef, nprobe, mode, now=later)
+        p = plain.search_dev(qd[1], B, k, now=later, hnsw_ef=ef, ivf_n_probe=nprobe, dim=d)
+        assert hyb.recent_count() == plain.recent_count() == 0 and hyb.historical_count() == plain.historical_count() == n
+        assert np.array_equal(p.counts, r.counts) and np.array_equal(p.ids, r.ids) and np.array_equal(bits(p.distances), bits(r.distances))
+        assert any(len(set(r.ids[b, : r.counts[b]].tolist())) < r.counts[b] for b in range(B))  # a row found in both parts
     comm.close()
 
 
