@@ -730,8 +730,8 @@ int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const
                g->d_adjU.as<uint32_t>(), g->stride0, g->strideU, g->n, s->dpad, g->entry, g->top_level, g->n_deleted ? 1u : 0u,
                nullptr, nullptr};
   if (!g->d_counters.p) {
-    HIPCHK(ctx, g->d_counters.ensure(16));
-    HIPCHK(ctx, hipMemsetAsync(g->d_counters.p, 0, 16, ctx->stream));
+    HIPCHK(ctx, g->d_counters.ensure(32));
+    HIPCHK(ctx, hipMemsetAsync(g->d_counters.p, 0, 32, ctx->stream));
   }
   gv.counters = (unsigned long long*)g->d_counters.p;
 #ifdef FVDB_GRAPH_STAMPS
@@ -877,11 +877,13 @@ int fvdb_graph_kernel_times(fvdb_graph* g, float* ms_sum, uint32_t* launches, ui
   *launches = 0;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  unsigned long long c[2] = {0, 0};
+  unsigned long long c[4] = {0, 0, 0, 0};  // rows scored, hops, queries searched again with the restated heaps, queries
   if (g->d_counters.p) {
-    HIPCHK(ctx, hipMemcpy(c, g->d_counters.p, 16, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemset(g->d_counters.p, 0, 16));
+    HIPCHK(ctx, hipMemcpy(c, g->d_counters.p, 32, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemset(g->d_counters.p, 0, 32));
   }
+  if (getenv("FVDB_GRAPH_DEBUG"))
+    fprintf(stderr, "[graph traversal] %llu queries, %llu searched again with the restated heaps (equal distances)\n", c[3], c[2]);
   if (rows_scored) *rows_scored = c[0];
   if (hops) *hops = c[1];
   const uint32_t n = std::min<uint32_t>(g->kev_n, 64);

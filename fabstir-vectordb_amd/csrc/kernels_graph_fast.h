@@ -204,7 +204,14 @@ __global__ __launch_bounds__(256, (R <= 8 ? 4 : (R <= 12 ? 3 : FVDB_FAST_WAVES16
   uint32_t hn = 0;   // lane i: node of the i-th nearest | expanded << 31
   float hd = 0.0f;   //         its distance
   uint32_t nN = 0;
-  uint32_t status = 0;  // 1: visited log overflow (host walk), 2: equal distances met (exact-heap kernel)
+  uint32_t status = 0;  // 1: visited log overflow (host walk), 2: equal distances met where the heap layout decides (exact-heap kernel)
+  // Equal distances inside the heaps (see kernels_graph_build.h for the argument): BinaryHeap's layout decides between
+  // equal keys only when two of them are at the top of a heap at once.  `amb`: two members shared the maximum when one had
+  // to leave (an expanded one is sent away; the search is the same unless the survivor is popped or ends up in the
+  // result).  `twin_*`: two candidates shared the minimum at a pop (expanded back to back in either order if neither
+  // expansion admits anything nearer).  Equal distances in the final list: the stable sort keeps the heap array's order.
+  float amb = __uint_as_float(0x7FC00000u), twin_d = 0.0f;  // NaN: none (compares equal to nothing)
+  uint32_t twin_left = 0;
   for (uint32_t layer = g.top_level + 1; layer-- > 0 && status == 0;) {
     const uint32_t ef = layer == 0 ? ef_final : 1;
     uint32_t nT = 1;
@@ -212,6 +219,8 @@ __global__ __launch_bounds__(256, (R <= 8 ? 4 : (R <= 12 ? 3 : FVDB_FAST_WAVES16
     nN = 1;
     hn = ep_node;
     hd = ep_d;
+    amb = __uint_as_float(0x7FC00000u);
+    twin_left = 0;
     if (lane == 0) {
       if (BYTES) visb[ep_node] = 1;
       else atomicOr(&vis[ep_node >> 5], 1u << (ep_node & 31));
@@ -227,6 +236,19 @@ __global__ __launch_bounds__(256, (R <= 8 ? 4 : (R <= 12 ? 3 : FVDB_FAST_WAVES16
       if (open == 0) break;
       const uint32_t cl = (uint32_t)__builtin_ctzll(open);
       const uint32_t node = __builtin_amdgcn_readlane(hn, cl);
+      {
+        // two candidates share the smallest distance: which one BinaryHeap::pop returns is its layout's business
+        const float dc = rlane_f(hd, cl);
+        const uint32_t holders = (uint32_t)__popcll(open & __ballot((uint32_t)lane < nN && hd == dc));
+        if (holders > 2 || dc == amb || (twin_left != 0 && (dc != twin_d || holders != twin_left))) {
+          status = 2;
+          break;
+        }
+        if (holders == 2 && twin_left == 0) {
+          twin_d = dc;
+          twin_left = 2;
+        }
+      }
       if ((uint32_t)lane == cl) hn |= 0x80000000u;
       uint32_t np = 0;
       if (layer == 0 || g.level[node] >= layer) {
@@ -308,9 +330,32 @@ __global__ __launch_bounds__(256, (R <= 8 ? 4 : (R <= 12 ? 3 : FVDB_FAST_WAVES16
           if (nN < ef || d < worst) {
             const uint32_t nd = __builtin_amdgcn_readlane(pn, i);
             const bool mine = (uint32_t)lane < nN;
-            if (__ballot(mine && hd == d)) {  // equal distances inside the heaps: their order is the reference's heap layout
+#ifdef FVDB_FAST_STRICT_TIES
+            if (__ballot(mine && hd == d)) {  // (A/B: the first form — any equal distance inside the heaps ends the attempt)
               status = 2;
               break;
+            }
+#endif
+            if (twin_left != 0 && d < twin_d) {  // the pair is not expanded back to back: the order matters
+              status = 2;
+              break;
+            }
+            if (nN == ef) {
+              // the maximum leaves (nearest.pop(), :528-530).  Two members sharing it: which one leaves is the layout's
+              // business — an EXPANDED one is sent away if there is one, so that a survivor that can still be popped is
+              // in this list too and its pop (if it comes to that) is seen
+              const uint64_t grp = __ballot(mine && hd == worst);
+              if (__popcll(grp) > 1) {
+                amb = worst;
+                const uint64_t ex = __ballot(mine && hd == worst && (hn >> 31) != 0);
+                const uint32_t last = nN - 1;
+                if (ex && ((ex >> last) & 1ull) == 0) {  // the last lane holds an unexpanded one: trade places with an expanded one
+                  const uint32_t l = (uint32_t)__builtin_ctzll(ex);
+                  const uint32_t a = __builtin_amdgcn_readlane(hn, l), z = __builtin_amdgcn_readlane(hn, last);
+                  if ((uint32_t)lane == l) hn = z;
+                  if ((uint32_t)lane == last) hn = a;
+                }
+              }
             }
             const uint32_t pos = __popcll(__ballot(mine && hd < d));
             const uint32_t up_n = dpp_wave_shr1(hn);
@@ -333,6 +378,16 @@ __global__ __launch_bounds__(256, (R <= 8 ? 4 : (R <= 12 ? 3 : FVDB_FAST_WAVES16
       t_acc[6] += 1;
 #endif
       if (status) break;
+      if (twin_left != 0) twin_left -= 1;
+    }
+    // the layer's result: equal distances inside it would come out in the heap array's order, and the survivor of a tied
+    // maximum is one of two legal members.  Only the part that is read counts: the first entry on the upper layers, the
+    // first k (and the pair at the cut) on layer 0 — all of it when soft-deleted nodes are filtered out afterwards.
+    if (status == 0) {
+      const uint32_t read = layer != 0 ? 1u : (g.any_deleted ? nN : min(nN, k + 1));
+      const bool in = (uint32_t)lane < read;
+      const float nxt = __uint_as_float(dpp_wave_shr1(__float_as_uint(hd)));  // lane i <- lane i-1
+      if (__ballot(in && lane > 0 && nxt == hd) || __ballot(in && hd == amb)) status = 2;
     }
     // ---- drop this layer's visited set ----
     if (nT <= tcap && status != 1) {
@@ -348,6 +403,10 @@ __global__ __launch_bounds__(256, (R <= 8 ? 4 : (R <= 12 ? 3 : FVDB_FAST_WAVES16
     // the layer's result is `nearest` in ascending order (:541-553); its first element enters the next layer
     ep_node = __builtin_amdgcn_readlane(hn, 0) & 0x7FFFFFFFu;
     ep_d = rlane_f(hd, 0);
+  }
+  if (lane == 0 && g.counters) {
+    atomicAdd(g.counters + 3, 1ull);
+    if (status == 2) atomicAdd(g.counters + 2, 1ull);
   }
   if (status == 2) {
     // equal distances met inside the heaps: this query is searched again, from the start, with the reference's heaps

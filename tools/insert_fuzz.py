@@ -60,9 +60,31 @@ def one_case(fv, orc, ctx, rng, case, only=-1):
             if nb[int(off[slot]):int(off[slot + 1])].tolist() != oh.neighbors(r, layer):
                 bad += 1
             slot += 1
+    # searches on the finished graph, device traversal against the oracle's walk: rows of the index itself among the
+    # queries (distance 0 and, with duplicates, equal distances), ef below / at / above the sorted-register form
+    nq = 96
+    q = np.ascontiguousarray(np.concatenate([x[g.integers(0, n, nq // 2)],
+                                             means[g.integers(0, n_comp, nq // 2)] + np.float32(sigma) * g.standard_normal((nq // 2, d)).astype(np.float32)]), np.float32)
+    if quant:
+        q = np.ascontiguousarray(np.round(q * 4) / 4, np.float32)
+    sbad = 0
+    for k, ef in ((10, 10), (10, 50), (5, 64), (20, 100)):
+        got, want = gh.search(q, k, ef), oh.batch_search(q, k, ef)
+        valid = np.arange(k)[None, :] < np.asarray(want[2])[:, None]  # entries past a row's count are padding
+        same = (np.array_equal(got.counts, want[2]) and np.array_equal(got.ids[valid], want[0][valid]) and
+                np.array_equal(np.ascontiguousarray(got.distances).view(np.uint32)[valid], np.ascontiguousarray(want[1]).view(np.uint32)[valid]))
+        sbad += 0 if same else 1
+        if not same and os.environ.get("FUZZ_VERBOSE"):
+            rows = [b for b in range(nq) if got.counts[b] != want[2][b] or not np.array_equal(got.ids[b][valid[b]], want[0][b][valid[b]]) or
+                    not np.array_equal(got.distances[b].view(np.uint32)[valid[b]], want[1][b].view(np.uint32)[valid[b]])]
+            b = rows[0]
+            print(f"   search k {k} ef {ef}: {len(rows)} of {nq} queries differ; query {b} (index row: {b < nq // 2}): counts {got.counts[b]} / {want[2][b]}\n"
+                  f"     got  {got.ids[b].tolist()}\n     want {want[0][b].tolist()}\n     got d  {got.distances[b].tolist()}\n     want d {want[1][b].tolist()}")
+    bad += sbad
     print(f"case {case:3d}: n {n:5d} d {d:3d} M {M:2d}/{M0:2d} ef {efc:3d} comps {n_comp:4d} sigma {sigma:.2f} dup {dup_frac:.2f} grid {int(quant)} "
           f"mode {mode} batches {len(cuts) - 1}: adopted {st['speculated_ok']:5d} stops {st['commit_stops']:5d} restarts {st['tie_restarts']:4d} "
-          f"host {st['host_path_inserts']:3d}  -> {'OK' if bad == 0 else 'MISMATCH in %d lists' % bad}", flush=True)
+          f"host {st['host_path_inserts']:3d} dev-fallbacks {gh.device_fallbacks():3d}  -> "
+          f"{'OK' if bad == 0 else 'MISMATCH in %d lists / search settings (%d of them searches)' % (bad, sbad)}", flush=True)
     return bad
 
 
