@@ -239,7 +239,7 @@ void fvdb_graph_destroy(fvdb_graph* g) {
   (void)hipSetDevice(g->store->ctx->device);
   (void)hipStreamSynchronize(g->store->ctx->stream);
   DBuf* bufs[] = {&g->d_level, &g->d_deleted, &g->d_ubase, &g->d_adj0, &g->d_adjU, &g->d_dist0, &g->d_distU, &g->d_stamp0,
-                  &g->d_stampU, &g->d_state, &g->d_spec, &g->d_elog, &g->s_patch, &g->s_codes, &g->s_q, &g->d_counters};
+                  &g->d_stampU, &g->d_state, &g->d_spec, &g->d_elog, &g->d_chg, &g->s_patch, &g->s_codes, &g->s_q, &g->d_counters};
   for (auto& b : g->s_visited) b.release();
   for (auto& b : g->s_touched) b.release();
   for (auto& b : g->s_spill) b.release();
@@ -536,7 +536,9 @@ int fvdb_graph_insert_linked(fvdb_graph* g, uint32_t first, uint32_t n, uint32_t
   static const int env_kmax = getenv("FVDB_BUILD_KMAX") ? atoi(getenv("FVDB_BUILD_KMAX")) : 0;
   // below this many nodes every insert lands in every other's neighbourhood: one at a time, no speculation
   static const uint32_t seq_below = getenv("FVDB_BUILD_SEQ_BELOW") ? (uint32_t)atoi(getenv("FVDB_BUILD_SEQ_BELOW")) : 256u;
-  const uint32_t Kmax = (uint32_t)std::max(1, std::min(env_k > 0 ? env_k : (env_kmax > 0 ? env_kmax : 128), 256));
+  // (a call never speculates further than it has nodes to link: the logs of a batch are 160 KB per (insert, layer) slot)
+  const uint32_t Kmax = std::min<uint32_t>((uint32_t)std::max(1, std::min(env_k > 0 ? env_k : (env_kmax > 0 ? env_kmax : 128), 256)),
+                                           std::max<uint32_t>(8, n));
   uint32_t K = env_k > 0 ? Kmax : std::min<uint32_t>(16, Kmax);  // adapts to the run length of adopted speculations
   // 0: the commit workgroup adopts speculated searches up to the first one an earlier insert of the batch invalidated,
   // searches that ONE itself (so every launch pair makes progress) and stops; the rest of the batch is speculated again,
