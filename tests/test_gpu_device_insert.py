@@ -260,3 +260,14 @@ def test_randomised_shapes_build_the_oracles_graph(fv, ctx):
         if insert_fuzz.one_case(fv, orc, ctx, rng, c, only):
             failed.append(c)
     assert not failed, failed
+
+
+def test_randomised_operation_sequences_match_the_oracle(fv, ctx):
+    # tools/hnsw_ops_fuzz.py: device batch inserts (one at a time / speculated), host-algorithm inserts, single inserts,
+    # soft deletes, vacuum, searches by the device traversal and by the host walk, in random order — the hand-overs
+    # between the device-resident graph and its host cache; every search and the final graph equal the oracle's
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import hnsw_ops_fuzz
+    rng = np.random.default_rng(1)
+    failed = [c for c in range(12) if hnsw_ops_fuzz.one_case(fv, orc, ctx, rng, c, c if c in (1, 4, 7, 10, 11) else -2)]
+    assert not failed, failed
