@@ -622,3 +622,16 @@ def test_hybrid_vacuum_matches_oracle(fv, ctx):
         h.search(q[:2], 3, 10)
     with pytest.raises(fv.FvdbError):
         h.insert(1000, x[40], 0)
+
+
+def test_randomised_hybrid_operation_sequences_match_the_oracle(fv, ctx):
+    # tools/hybrid_ops_fuzz.py: inserts at random ages (graph / lists), time moving on (per-search auto-migration),
+    # searches with host- and device-resident queries (blocking and begin/end), deletes (with the reference's
+    # looked-for-in-the-wrong-part failures), explicit migration — results, counters and failures equal the oracle's
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import hybrid_ops_fuzz
+    rng = np.random.default_rng(1)
+    failed = [c for c in range(24) if hybrid_ops_fuzz.one_case(fv, orc, ctx, rng, c, c if c % 3 == 2 else -2)]
+    assert not failed, failed
