@@ -507,6 +507,9 @@ struct HNSW {
   int insert(uint64_t id, const float* v, size_t dim, int64_t forced_level) {
     if (index_of.count(id)) return ORC_DUPLICATE;
     if (has_dim && dim != d) return ORC_DIM_MISMATCH;
+    // after a vacuum that removed the entry point's node the reference unwraps a missing node (:268-274: a panic —
+    // the insert fails); reported as an error, with nothing changed
+    if (has_entry && !get(entry_point)) return ORC_NOT_FOUND;
     if (!has_dim) {
       d = dim;
       has_dim = true;

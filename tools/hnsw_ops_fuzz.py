@@ -48,7 +48,10 @@ def one_case(fv, orc, ctx, rng, case, only=-1, log=print):
     at, bad, trail = 0, 0, []
     alive = []
     for s in range(steps):
+      try:
         op = g.choice(["batch_dev", "batch_dev", "batch_spec", "batch_host", "single", "delete", "search", "search", "vacuum"])
+        if os.environ.get("FUZZ_TRACE"):
+            print(f"   step {s}: {op} (nodes so far {at})", flush=True)
         if op.startswith("batch") or op == "single":
             cnt = 1 if op == "single" else int(g.integers(2, 700))
             cnt = min(cnt, total - at)
@@ -59,14 +62,31 @@ def one_case(fv, orc, ctx, rng, case, only=-1, log=print):
             else:
                 gh.set_device_insert(True, 2 if op == "batch_spec" else int(g.choice([0, 1])))
             sl = slice(at, at + cnt)
+
+            def attempt(f):
+                try:
+                    return ("ok", f())
+                except Exception as e:  # noqa: BLE001
+                    return ("err", type(e).__name__)
             if op == "single":
-                gh.insert(int(ids[at]), x[at], int(levels[at]))
-                oh.insert(int(ids[at]), x[at], int(levels[at]))
+                ra = attempt(lambda: gh.insert(int(ids[at]), x[at], int(levels[at])))
+                rb = attempt(lambda: oh.insert(int(ids[at]), x[at], int(levels[at])))
+                g_ok, o_ok, g_none = ra[0] == "ok", rb[0] == "ok", ra[0] != "ok"
             else:
-                gh.batch_insert(ids[sl], x[sl], levels[sl])
-                oh.batch_insert(ids[sl], x[sl], levels[sl])
-            alive += list(range(at, at + cnt))
-            at += cnt
+                # (the oracle's batch stops at the first row that fails and raises; the product counts failures and goes on)
+                ra = attempt(lambda: gh.batch_insert(ids[sl], x[sl], levels[sl]))
+                rb = attempt(lambda: oh.batch_insert(ids[sl], x[sl], levels[sl]))
+                g_ok, o_ok = ra[0] == "ok" and ra[1][1] == 0, rb[0] == "ok"
+                g_none = ra[0] != "ok" or ra[1][0] == 0
+            # after a vacuum that removed the entry point every insert fails on both sides (src/hnsw/core.rs:268-274)
+            if g_ok != o_ok or (not g_ok and not g_none):
+                bad += 1
+                op += "!"
+            if g_ok:
+                alive += list(range(at, at + cnt))
+                at += cnt
+            else:
+                op += "(failed on both)"
         elif op == "delete" and alive:
             for i in g.choice(alive, size=min(len(alive), int(g.integers(1, 30))), replace=False).tolist():
                 gh.mark_deleted(int(ids[i]))
@@ -79,10 +99,22 @@ def one_case(fv, orc, ctx, rng, case, only=-1, log=print):
             gh.set_device_traversal(bool(g.integers(0, 2)))
             q = np.ascontiguousarray(np.concatenate([x[g.integers(0, at, 16)], x[g.integers(0, total, 16)]]), np.float32)
             k, ef = (int(v) for v in g.choice([[5, 5], [10, 50], [10, 64], [20, 120]]))
-            ok = same_results(gh.search(q, k, ef), oh.batch_search(q, k, ef), k)
+            # (after a vacuum that removed the entry point the reference's search fails — "Entry point node not found",
+            # src/hnsw/core.rs:422-429 — and so must both sides)
+            def outcome(f):
+                try:
+                    return f()
+                except Exception as e:  # noqa: BLE001
+                    return type(e).__name__
+            a, b = outcome(lambda: gh.search(q, k, ef)), outcome(lambda: oh.batch_search(q, k, ef))
+            ok = (isinstance(a, str) and isinstance(b, str)) or (not isinstance(a, str) and not isinstance(b, str) and same_results(a, b, k))
             bad += 0 if ok else 1
             op = f"search(dev={gh.device_traversal()},k={k},ef={ef}){'' if ok else '!'}"
         trail.append(op)
+      except Exception as e:  # noqa: BLE001
+        trail.append(f"{op}:{type(e).__name__}({e})")
+        bad += 1
+        break
     gbad = 0
     if at:
         gbad += 0 if gh.entry_point() == oh.entry_point() else 1
