@@ -232,3 +232,16 @@ def test_split_stages_and_slots_match_the_one_call_search(fv, ctx):
                 c.free(b_)
     finally:
         other.close()
+
+
+def test_randomised_shapes_search_like_the_oracle(fv, ctx):
+    # tools/ivf_fuzz.py: rows, dimension, lists, probes, k, batch size, cluster structure, exact duplicates, vectors on a
+    # coarse grid, soft deletes, queries that are rows of the index — the whole chain (coarse ranking, threshold, fp16
+    # filter, refinement, select, exact rescans) against the oracle, four searches per index
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ivf_fuzz
+    rng = np.random.default_rng(1)
+    failed = [c for c in range(30) if ivf_fuzz.one_case(fv, orc, ctx, rng, c, c if c % 3 == 0 else -2)]
+    assert not failed, failed
