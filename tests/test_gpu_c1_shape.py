@@ -82,10 +82,11 @@ def test_c1_sequential_insert_graph_and_searches_match_oracle(fv, ctx, generator
     assert st["host_path_inserts"] == 0 and st["n_done"] == N
     print(f"[c1 {generator}] device insert: {st}")
     # build time against the CPU oracle's (single thread, the reference's own cost model).  On the mixture the device
-    # build is the faster one.  The reference bench's generator walks a line — consecutive inserts are each other's
+    # build takes well under half the oracle's time.  The reference bench's generator walks a line — consecutive inserts are each other's
     # nearest neighbours, so no two inserts of a batch are independent, and every search ties and takes the restated
     # heaps: that data is built one insert at a time at the latency of ONE workgroup, somewhat behind a CPU core.
-    assert t2 - t1 <= (1.0 if generator == "survey_mixture" else 1.6) * (t1 - t0) + 1.0, (t2 - t1, t1 - t0)
+    # (measured: 2.0 s against 7.3 s on the mixture, 8.5 s against 6.2 s on the reference bench's generator)
+    assert t2 - t1 <= (0.5 if generator == "survey_mixture" else 1.6) * (t1 - t0) + 1.0, (t2 - t1, t1 - t0)
     if generator == "survey_mixture":
         # self-match (tests/hnsw/core.rs:199-226) at this shape: the reference's nearest-M neighbour selection (no
         # diversity heuristic) leaves well-separated components poorly connected, so ef = 50 finds ~70 % of the stored
