@@ -492,6 +492,8 @@ def main():
                        "hnsw_traversal": args.hnsw_traversal, "batches_in_flight": depth, "query_batches": nb,
                        "host_collect_merge_ms_per_step": None if host_collect_ms is None else round(host_collect_ms, 4),
                        "other_traversal_mode": other, "hnsw_device_fallbacks": hnsw.device_fallbacks(),
+                       "hnsw_tie_restarts": dict(zip(("queries_served_by_the_traversal_kernel", "searched_again_with_restated_heaps"),
+                                                     hnsw.tie_restarts())),
                        "ivf_scan_fallbacks": int(ivf_scan_fallbacks(ctx_ivf, hyb.ivf())),
                        "recall_at_10": round(recall, 4), "recall_target": args.recall_target,
                        "recall_held_out_batches": None if held_out is None else round(held_out, 4), "sweep": sweep,

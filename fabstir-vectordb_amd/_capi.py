@@ -117,6 +117,7 @@ SIGNATURES = {
     "fvdb_event_record": (i32, [vp, vp]),
     "fvdb_event_wait": (i32, [vp, vp]),
     "fvdb_graph_kernel_times": (i32, [vp, f32p, u32p, u64p, u64p]),
+    "fvdb_graph_tie_restarts": (i32, [vp, u64p, u64p]),
     "fvdb_scorer_launch": (i32, [vp, u32, u32]),
     "fvdb_scorer_wait": (i32, [vp]),
     "fvdb_top_k_indices": (i32, [vp, f32p, u32, u64, u32, u64p, u32p]),

@@ -38,6 +38,7 @@ struct fvdb_graph {
   uint64_t upload_bytes = 0;        // host -> device bytes of graph STRUCTURE (not vectors) since creation
   fvdb_graph_insert_stats last{};
   DBuf s_q, d_counters;
+  uint64_t tot_queries = 0, tot_again = 0;  // traversal counters [3], [2] folded in at every fvdb_graph_kernel_times
   static constexpr uint32_t kSlots = 16;  // batches that may be in flight at once, each on its own stream
   DBuf s_visited[kSlots], s_touched[kSlots], s_spill[kSlots];
   uint32_t vis_B[kSlots] = {}, vis_words = 0, vis_tcap = 0, vis_stride = 0;
@@ -873,6 +874,17 @@ int fvdb_graph_search_dev_slot(fvdb_graph* g, fvdb_ctx* on, uint32_t slot, const
   return FVDB_OK;
 }
 
+int fvdb_graph_tie_restarts(fvdb_graph* g, uint64_t* queries, uint64_t* searched_again) {
+  fvdb_ctx* ctx = g->store->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipDeviceSynchronize());  // searches may run on several streams
+  unsigned long long c[4] = {0, 0, 0, 0};
+  if (g->d_counters.p) HIPCHK(ctx, hipMemcpy(c, g->d_counters.p, 32, hipMemcpyDeviceToHost));
+  if (queries) *queries = g->tot_queries + c[3];
+  if (searched_again) *searched_again = g->tot_again + c[2];
+  return FVDB_OK;
+}
+
 int fvdb_graph_kernel_times(fvdb_graph* g, float* ms_sum, uint32_t* launches, uint64_t* rows_scored, uint64_t* hops) {
   fvdb_ctx* ctx = g->store->ctx;
   *ms_sum = 0.0f;
@@ -884,6 +896,8 @@ int fvdb_graph_kernel_times(fvdb_graph* g, float* ms_sum, uint32_t* launches, ui
     HIPCHK(ctx, hipMemcpy(c, g->d_counters.p, 32, hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemset(g->d_counters.p, 0, 32));
   }
+  g->tot_queries += c[3];
+  g->tot_again += c[2];
   if (getenv("FVDB_GRAPH_DEBUG"))
     fprintf(stderr, "[graph traversal] %llu queries, %llu searched again with the restated heaps (equal distances)\n", c[3], c[2]);
   if (rows_scored) *rows_scored = c[0];

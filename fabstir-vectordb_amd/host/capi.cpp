@@ -114,6 +114,7 @@ void fvh_hnsw_set_threads(void* p, int t) { ((HNSWIndex*)p)->set_threads(t); }
 void fvh_hnsw_set_device_traversal(void* p, int on) { ((HNSWIndex*)p)->set_device_traversal(on != 0); }
 int fvh_hnsw_device_traversal(void* p) { return ((HNSWIndex*)p)->device_traversal(); }
 uint64_t fvh_hnsw_device_fallbacks(void* p) { return ((HNSWIndex*)p)->device_fallbacks(); }
+int fvh_hnsw_tie_restarts(void* p, uint64_t* queries, uint64_t* again) { return ((HNSWIndex*)p)->tie_restarts(queries, again); }
 int fvh_hnsw_graph_kernel_times(void* p, float* ms_sum, uint32_t* launches, uint64_t* rows_scored, uint64_t* hops) {
   return ((HNSWIndex*)p)->graph_kernel_times(ms_sum, launches, rows_scored, hops);
 }

@@ -205,6 +205,11 @@ class HNSWIndex {
     *rows_scored = *hops = 0;
     return graph_ ? fvdb_graph_kernel_times(graph_, ms_sum, launches, rows_scored, hops) : 0;
   }
+  // queries served by the traversal kernel / searched a second time with the restated heaps (equal distances)
+  int tie_restarts(uint64_t* queries, uint64_t* again) {
+    *queries = *again = 0;
+    return graph_ ? fvdb_graph_tie_restarts(graph_, queries, again) : 0;
+  }
 
  private:
   struct Query {

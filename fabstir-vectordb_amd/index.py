@@ -71,6 +71,7 @@ HOST_SIGNATURES = {
     "fvh_hnsw_device_traversal": (i32, [vp]),
     "fvh_hnsw_device_fallbacks": (u64, [vp]),
     "fvh_hnsw_graph_kernel_times": (i32, [vp, f32p, u32p, u64p, u64p]),
+    "fvh_hnsw_tie_restarts": (i32, [vp, u64p, u64p]),
     "fvh_hybrid_new": (vp, [vp, vp, dbl, u64, i32, u64, u32, u32, u32, u64, u32, u32, u32, u32, u64]),
     "fvh_hybrid_free": (None, [vp]),
     "fvh_hybrid_initialize": (i32, [vp, f32p, u64, u32]),
@@ -469,6 +470,13 @@ class HNSWIndex(_Base):
         ms, n, rows, hops = C.c_float(0), C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
         self.lib.fvh_hnsw_graph_kernel_times(self.h, C.byref(ms), C.byref(n), C.byref(rows), C.byref(hops))
         return float(ms.value), int(n.value), int(rows.value), int(hops.value)
+
+
+    def tie_restarts(self):
+        """(queries served by the device traversal, queries it searched again with the restated heaps) since creation."""
+        q, a = C.c_uint64(0), C.c_uint64(0)
+        self.lib.fvh_hnsw_tie_restarts(self.h, C.byref(q), C.byref(a))
+        return int(q.value), int(a.value)
 
 
 class HybridIndex(_Base):

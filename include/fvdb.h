@@ -394,6 +394,10 @@ uint64_t fvdb_graph_upload_bytes(fvdb_graph* g);
  * <= 64 launches of the traversal kernel since the previous call, and how many were summed; and (always) the
  * rows scored and hops taken by all queries since the previous call (either may be NULL).  Synchronises. */
 int fvdb_graph_kernel_times(fvdb_graph* g, float* ms_sum, uint32_t* launches, uint64_t* rows_scored, uint64_t* hops);
+/* Since the graph was created: queries the traversal kernel served, and how many of them it searched a second time with
+ * the reference's BinaryHeaps restated because equal distances met where the heap layout decides (src/hnsw/core.rs:469-554;
+ * such a query is the slowest of its launch).  Synchronises. */
+int fvdb_graph_tie_restarts(fvdb_graph* g, uint64_t* queries, uint64_t* searched_again);
 
 /* ---- multi-GPU: inverted lists sharded across the GPUs of a node, RCCL over xGMI -------------------------
  * (BASELINE config C4; SURVEY §8e.  The reference has no distributed execution: what is preserved is the result —
